@@ -1,0 +1,191 @@
+"""Pin the CPU oracle (oracle/mvrt_oracle.cpp) before anything is allowed to trust it.
+
+Two kinds of pins (DESIGN.md "Oracle"):
+  * the reference sources that compile as they lie (morton.hpp, smhasher MurmurHash3.cpp ->
+    oracle/_ref), exercised the way the reference's own unittest.cpp does (:106-132, :183-227);
+  * golden numbers the survey captured from the reference source (tests/golden/survey_appendix_a.json).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from common import bunny_tris, golden, hdr_bytes, probe_camera
+from oracle import oracle as O
+
+G = golden()
+
+
+def test_struct_sizes():
+    assert O.struct_sizes() == G["struct_sizes"]
+
+
+def test_murmur_known_answers():
+    assert O.murmur(0, [12345]) == int(G["murmur_seed0_12345"], 16)
+    assert O.murmur(0, [123456]) == int(G["murmur_pixel_123456_stream"], 16)
+
+
+def test_murmur_vs_reference_smhasher():
+    """unittest.cpp:106-132 'MurmurHash3.compatibility': 0-15 words, random seed."""
+    ref = O.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(1)
+    for _ in range(20000):
+        n = int(rng.integers(0, 16))
+        xs = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+        s = int(rng.integers(0, 2**32))
+        h0 = ref.ref_murmur3_x86_32(xs.ctypes.data, n, s)
+        assert O.murmur(s, xs) == h0
+
+
+def test_morton_vs_reference_header():
+    """unittest.cpp:183-216 'morton.encodedecode': naive == PDEP == magic bits, decoders round-trip."""
+    rng = np.random.default_rng(2)
+    xyz = rng.integers(0, 1 << 21, size=(200000, 3), dtype=np.uint64).astype(np.uint32)
+    mine = O.morton_encode_batch(xyz)
+    ref = O.load_ref()
+    if ref is not None:
+        a, b, c = (np.zeros(len(xyz), np.uint64) for _ in range(3))
+        ref.ref_morton_batch(xyz.ctypes.data, len(xyz), a.ctypes.data, b.ctypes.data, c.ctypes.data)
+        assert (a == b).all() and (a == c).all() and (a == mine).all()
+    for i in range(0, 2000):
+        x, y, z = (int(v) for v in xyz[i])
+        m = O.morton_encode(x, y, z)
+        assert m == O.morton_encode_naive(x, y, z) == int(mine[i])
+        assert O.morton_decode(m) == (x, y, z)
+
+
+def test_morton_sort_bits():
+    """unittest.cpp:218-227: popcount of the max morton code of a 2^i grid is 3*i."""
+    for i in range(21):
+        r = 1 << i
+        assert bin(O.morton_encode(r - 1, r - 1, r - 1)).count("1") == 3 * i
+
+
+def test_reverse_bits_involution_and_owen_bijection():
+    """unittest.cpp:66-104."""
+    rng = np.random.default_rng(3)
+    for x in rng.integers(0, 2**32, size=2000, dtype=np.uint64):
+        assert O.reverse_bits(O.reverse_bits(int(x))) == int(x)
+    for seed in rng.integers(0, 2**32, size=300, dtype=np.uint64):
+        got = {O.nested_uniform_scramble(i, int(seed)) & 63 for i in range(64)}
+        assert len(got) == 64
+    for x in rng.integers(0, 2**32, size=2000, dtype=np.uint64):
+        s = O.scramble_f32(O.uniformf(int(x)), 192324)
+        assert 0.0 <= s < 1.0
+
+
+def test_bsearch_matches_membership():
+    """unittest.cpp:40-64."""
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        xs = np.sort(rng.integers(0, 100, size=100)).astype(np.int32)
+        for x in rng.integers(0, 120, size=50):
+            assert (O.bsearch(xs, int(x)) != -1) == bool((xs == x).any())
+
+
+def test_rng_and_scramble_known_answers():
+    assert list(O.pcg32(0, 2525, 2)) == G["pcg32_seed0_stream2525_first2"]
+    assert O.nested_uniform_scramble(5, 77) == G["nested_uniform_scramble_5_77"]
+    assert O.scramble_f32(0.25, 99) == np.float32(G["scramble_f32_0p25_99"])
+
+
+def test_pmj_table_hash_and_samples():
+    tab = O.pmj_table()
+    assert tab.nbytes == G["pmj_table_bytes"]
+    assert hashlib.sha256(tab.tobytes()).hexdigest() == G["pmj_table_sha256"]
+    assert np.allclose(tab[:4].reshape(2, 2), np.array(G["pmj_first_pairs"], np.float32), rtol=0, atol=1e-9)
+    assert np.array_equal(O.pmj_sample2d(5, 3, 0xDEADBEEF), np.array(G["sample2d_5_3_deadbeef"], np.float32))
+
+
+def test_lambert_known_answer():
+    got = O.sample_lambertian(0.3, 0.7, [0, 1, 0], math_mode=0)
+    assert np.array_equal(got, np.array(G["lambert_0p3_0p7_plusY_libm"], np.float32))
+    det = O.sample_lambertian(0.3, 0.7, [0, 1, 0], math_mode=1)
+    assert np.abs(det - got).max() < 1e-6
+
+
+@pytest.fixture(scope="module")
+def bunny256():
+    return O.build_scene_from_triangles(bunny_tris(), 256)
+
+
+def test_bunny256_build_counts(bunny256):
+    g = G["bunny"]["256"]
+    assert np.allclose(bunny256.origin, np.array(G["bunny"]["origin"], np.float32), rtol=0, atol=0)
+    assert np.float32(bunny256.dps) == np.float32(G["bunny"]["dps_256"])
+    assert bunny256.dumped == g["dumped"]
+    assert len(bunny256.morton) == g["voxels"]
+    assert len(bunny256.nodes) == g["dag_nodes"]
+    assert len(O.build_octree(bunny256.morton, 256, dag=False)) == g["naive_nodes"]
+    assert bunny256.has_emission == 0
+
+
+def test_bunny256_primary_rays(bunny256):
+    g = G["bunny"]["256"]["primary_1080p"]
+    cam = probe_camera(bunny256.origin, bunny256.dps, 256)
+    r = bunny256.render_primary(cam, 1920, 1080, threads=8)
+    hit = r["t"] != O.MAX_FLOAT
+    nm = r["nMajor"][hit]
+    assert int(hit.sum()) == g["hits"]
+    assert [int((nm == k).sum()) for k in (0, 1, 2)] == g["nMajor_z_x_y"]
+    assert int(r["vIndex"][hit].astype(np.uint64).sum()) == g["sum_vIndex"]
+    assert abs(float(r["descents"].mean()) - g["mean_descents_all_pixels"]) < 0.05
+    # DAG sharing must not alter traversal (Appendix A): naive build gives identical hits/t
+    naive = O.Scene(O.build_octree(bunny256.morton, 256, dag=False), bunny256.attrs, bunny256.origin, bunny256.dps, 256)
+    r2 = naive.render_primary(cam, 1920, 1080, threads=8)
+    assert np.array_equal(r2["t"], r["t"]) and np.array_equal(r2["nMajor"], r["nMajor"]) and np.array_equal(r2["vIndex"], r["vIndex"])
+    # max stack depth = log2(gridRes)
+    tr = bunny256.trace(np.tile(cam[0:3], (1920 * 1080, 1)), np.zeros((1, 3), np.float32) + _all_dirs(cam, 1920, 1080), threads=8)
+    assert tr["maxSp"] <= G["bunny"]["256"]["max_sp"]
+
+
+def _all_dirs(cam, W, H):
+    xs = (np.arange(W, dtype=np.float32) + np.float32(0.5)) / np.float32(W)
+    ys = (np.arange(H, dtype=np.float32) + np.float32(0.5)) / np.float32(H)
+    tan = cam[12]
+    mx = (-tan + (tan - (-tan)) * xs) * np.float32(W) / np.float32(H)
+    my = tan + (-tan - tan) * ys
+    d = cam[9:12][None, None, :] * mx[None, :, None] + cam[6:9][None, None, :] * my[:, None, None] + cam[3:6][None, None, :]
+    return d.reshape(-1, 3).astype(np.float32)
+
+
+def test_render_normals_bytesum(bunny256):
+    cam = probe_camera(bunny256.origin, bunny256.dps, 256)
+    r = bunny256.render_primary(cam, 256, 144, threads=4)
+    assert int(r["rgba"].astype(np.uint64).sum()) == G["render_normals_256x144_bytesum"]
+
+
+def test_bunny1024_counts_and_hits():
+    """1024^3: voxel/node counts and hit count are exact; the nMajor split and sum(vIndex) sit within
+    +-1 of the survey's numbers (one edge pixel; the survey's probe driver was compiled with
+    clang's default contraction for the camera arithmetic, ours is contraction-free)."""
+    g = G["bunny"]["1024"]
+    sc = O.build_scene_from_triangles(bunny_tris(), 1024)
+    assert (sc.dumped, len(sc.morton), len(sc.nodes)) == (g["dumped"], g["voxels"], g["dag_nodes"])
+    cam = probe_camera(sc.origin, sc.dps, 1024)
+    r = sc.render_primary(cam, 1920, 1080, threads=8)
+    hit = r["t"] != O.MAX_FLOAT
+    nm = r["nMajor"][hit]
+    assert int(hit.sum()) == g["primary_1080p"]["hits"]
+    got = [int((nm == k).sum()) for k in (0, 1, 2)]
+    assert max(abs(a - b) for a, b in zip(got, g["primary_1080p"]["nMajor_z_x_y"])) <= 1
+    assert abs(int(r["vIndex"][hit].astype(np.uint64).sum()) - g["primary_1080p"]["sum_vIndex"]) <= 2
+    assert abs(float(r["descents"].mean()) - g["primary_1080p"]["mean_descents_all_pixels"]) < 0.05
+
+
+def test_hdri_sat_golden():
+    g = G["hdri_monks_forest_s"]
+    rgba, w, h = O.decode_rgbe(hdr_bytes())
+    assert (w, h) == (g["width"], g["height"])
+    H = O.HDRI(rgba, w, h, rgba, w, h, math_mode=0)
+    assert int(H.sat(0)[100]) == g["uniform_sat_100"]
+    for i in range(7):
+        s = H.sat(i)
+        assert int(s[-1]) == g["every_sat_last"]
+        assert (np.diff(s.reshape(h, w).astype(np.int64), axis=1) >= 0).all()
+    # deterministic-math tables differ from libm tables by < 2^-24 of full scale
+    Hd = O.HDRI(rgba, w, h, rgba, w, h, math_mode=1)
+    for i in range(7):
+        assert np.abs(H.sat(i).astype(np.int64) - Hd.sat(i).astype(np.int64)).max() < 256
