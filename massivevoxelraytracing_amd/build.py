@@ -1,0 +1,56 @@
+"""Build libmvrt_hip.so (the C-ABI library) for gfx950 with hipcc, in-tree.
+
+    python -m massivevoxelraytracing_amd.build [--force]
+
+-ffp-contract=off is part of the contract, not an optimisation choice: every fp32 traversal decision
+must equal the CPU oracle's (DESIGN.md "FP rules").
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmvrt_hip.so")
+SOURCES = ["api.hip", "kernels_rt.hip", "kernels_setup.hip", "svo_build.hip"]
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+    "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", f) for f in ("mvrt.h", "mvrt_detmath.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), src))
+        objs.append(obj)
+    for p, src in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,897 @@
+// api.hip -- the C-ABI of libmvrt_hip.so (include/mvrt.h): host objects that own device memory and
+// launch the kernels.  Mirrors the reference's host structs IntersectorOctreeGPU
+// (IntersectorOctreeGPU.hpp:21-275) and PathTracer (PathTracer.hpp:14-170) behind opaque handles.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mvrt.h"
+#include "launch.h"
+
+#define MVRT_EXPORT extern "C" __attribute__( ( visibility( "default" ) ) )
+
+static thread_local char g_err[1024] = "";
+void mvrtSetError( const char* fmt, ... )
+{
+	va_list ap;
+	va_start( ap, fmt );
+	vsnprintf( g_err, sizeof( g_err ), fmt, ap );
+	va_end( ap );
+}
+MVRT_EXPORT const char* mvrt_last_error( void ) { return g_err; }
+
+#define REQUIRE( cond, ... )          \
+	do                                \
+	{                                 \
+		if( !( cond ) )               \
+		{                             \
+			mvrtSetError( __VA_ARGS__ ); \
+			return 1;                 \
+		}                             \
+	} while( 0 )
+
+// ---- runtime ------------------------------------------------------------------------------------------
+MVRT_EXPORT int mvrt_device_count( int* count )
+{
+	MVRT_HIP( hipGetDeviceCount( count ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_set_device( int device )
+{
+	MVRT_HIP( hipSetDevice( device ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_device_name( char* buf, int bufLen )
+{
+	int dev = 0;
+	MVRT_HIP( hipGetDevice( &dev ) );
+	hipDeviceProp_t p;
+	MVRT_HIP( hipGetDeviceProperties( &p, dev ) );
+	snprintf( buf, bufLen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount );
+	return 0;
+}
+MVRT_EXPORT int mvrt_stream_create( void** stream )
+{
+	hipStream_t s;
+	MVRT_HIP( hipStreamCreate( &s ) );
+	*stream = (void*)s;
+	return 0;
+}
+MVRT_EXPORT int mvrt_stream_destroy( void* stream )
+{
+	MVRT_HIP( hipStreamDestroy( (hipStream_t)stream ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_stream_synchronize( void* stream )
+{
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_device_synchronize( void )
+{
+	MVRT_HIP( hipDeviceSynchronize() );
+	return 0;
+}
+MVRT_EXPORT int mvrt_malloc( void** dev, uint64_t bytes )
+{
+	MVRT_HIP( hipMalloc( dev, bytes ? bytes : 1 ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_free( void* dev )
+{
+	if( dev ) MVRT_HIP( hipFree( dev ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_memcpy_h2d( void* dev, const void* host, uint64_t bytes, void* stream )
+{
+	MVRT_HIP( hipMemcpyAsync( dev, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream ) );
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_memcpy_d2h( void* host, const void* dev, uint64_t bytes, void* stream )
+{
+	MVRT_HIP( hipMemcpyAsync( host, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream ) );
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+	return 0;
+}
+
+// small RAII device buffer (role of hipUtil.hpp:48-74 Buffer)
+struct DevBuf
+{
+	void* p = nullptr;
+	uint64_t bytes = 0;
+	int alloc( uint64_t b )
+	{
+		release();
+		bytes = b;
+		MVRT_HIP( hipMalloc( &p, b ? b : 1 ) );
+		return 0;
+	}
+	void release()
+	{
+		if( p ) (void)hipFree( p );
+		p = nullptr;
+		bytes = 0;
+	}
+	~DevBuf() { release(); }
+	DevBuf() {}
+	DevBuf( const DevBuf& ) = delete;
+	void operator=( const DevBuf& ) = delete;
+	template <class T> T* as() const { return (T*)p; }
+};
+
+// ---- IntersectorOctreeGPU -------------------------------------------------------------------------------
+struct mvrt_svo
+{
+	Node64* nodes = nullptr;
+	uint8_t* masks = nullptr;
+	uint2* attrs = nullptr;
+	uint64_t* morton = nullptr; // only after build()
+	mvrt_svo_info info;
+	uint8_t rootMask = 0;
+	mvrt_svo()
+	{
+		memset( &info, 0, sizeof( info ) );
+		info.emissionScale = 7.5f; // IntersectorOctreeGPU.hpp:273
+	}
+	void cleanUp() // :26-38
+	{
+		if( nodes ) (void)hipFree( nodes );
+		if( masks ) (void)hipFree( masks );
+		if( attrs ) (void)hipFree( attrs );
+		if( morton ) (void)hipFree( morton );
+		nodes = nullptr;
+		masks = nullptr;
+		attrs = nullptr;
+		morton = nullptr;
+		float es = info.emissionScale;
+		memset( &info, 0, sizeof( info ) );
+		info.emissionScale = es;
+	}
+	SvoDev dev() const
+	{
+		SvoDev d;
+		d.nodes = nodes;
+		d.masks = masks;
+		d.attrs = attrs;
+		d.nNodes = info.numberOfNodes;
+		d.nVoxels = info.numberOfVoxels;
+		d.lower = mk3( info.lower[0], info.lower[1], info.lower[2] );
+		d.upper = mk3( info.upper[0], info.upper[1], info.upper[2] );
+		d.dps = info.dps;
+		d.emissionScale = info.emissionScale;
+		d.hasEmission = info.hasEmission;
+		d.embedded = info.embeddedMask;
+		d.levels = info.levels;
+		d.rootIndex = info.numberOfNodes - 1; // root = last node, :250
+		d.rootMask = rootMask;
+		return d;
+	}
+};
+
+static int ilog2Exact( int v )
+{
+	int l = 0;
+	while( ( 1 << l ) < v ) l++;
+	return ( 1 << l ) == v ? l : -1;
+}
+static void setBounds( mvrt_svo* s, const float origin[3], float dps, int gridRes )
+{
+	// IntersectorOctreeGPU.hpp:78-80: m_upper = origin + float3{dps,dps,dps} * (float)gridRes
+	for( int k = 0; k < 3; k++ )
+	{
+		s->info.lower[k] = origin[k];
+		s->info.upper[k] = origin[k] + dps * (float)gridRes;
+	}
+	s->info.dps = dps;
+	s->info.gridRes = gridRes;
+	s->info.levels = ilog2Exact( gridRes );
+}
+
+MVRT_EXPORT int mvrt_svo_create( mvrt_svo** out )
+{
+	*out = new mvrt_svo();
+	return 0;
+}
+MVRT_EXPORT int mvrt_svo_destroy( mvrt_svo* svo )
+{
+	if( svo )
+	{
+		svo->cleanUp();
+		delete svo;
+	}
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_t numberOfNodes, const void* attribs8Host, uint32_t numberOfVoxels, const float origin[3],
+								 float dps, int gridRes, int hasEmission, int embeddedMask, void* stream )
+{
+	REQUIRE( svo && nodes68Host && numberOfNodes > 0, "mvrt_svo_upload: empty octree" );
+	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
+	REQUIRE( !embeddedMask || numberOfNodes < 0xFFFFFFu, "embedded masks need fewer than 0xFFFFFF nodes (IntersectorOctreeGPU.hpp:231), got %u", numberOfNodes );
+	hipStream_t st = (hipStream_t)stream;
+	svo->cleanUp();
+	DevBuf raw;
+	if( raw.alloc( (uint64_t)numberOfNodes * 68 ) ) return 1;
+	MVRT_HIP( hipMemcpyAsync( raw.p, nodes68Host, (uint64_t)numberOfNodes * 68, hipMemcpyHostToDevice, st ) );
+	MVRT_HIP( hipMalloc( (void**)&svo->nodes, (uint64_t)numberOfNodes * sizeof( Node64 ) ) );
+	MVRT_HIP( hipMalloc( (void**)&svo->masks, numberOfNodes ) );
+	MVRT_HIP( hipMalloc( (void**)&svo->attrs, (uint64_t)( numberOfVoxels ? numberOfVoxels : 1 ) * 8 ) );
+	if( numberOfVoxels ) MVRT_HIP( hipMemcpyAsync( svo->attrs, attribs8Host, (uint64_t)numberOfVoxels * 8, hipMemcpyHostToDevice, st ) );
+	if( launchConvertNodes( raw.as<uint8_t>(), numberOfNodes, svo->nodes, svo->masks, st ) ) return 1;
+	svo->info.numberOfNodes = numberOfNodes;
+	svo->info.numberOfVoxels = numberOfVoxels;
+	svo->info.hasEmission = hasEmission ? 1 : 0;
+	svo->info.embeddedMask = embeddedMask ? 1 : 0;
+	svo->info.totalDumpedVoxels = 0;
+	setBounds( svo, origin, dps, gridRes );
+	svo->rootMask = ( (const uint8_t*)nodes68Host )[(uint64_t)( numberOfNodes - 1 ) * 68];
+	MVRT_HIP( hipStreamSynchronize( st ) );
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_svo_build( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
+								const float origin[3], float dps, int gridRes )
+{
+	REQUIRE( svo && verticesHost && nVertices >= 3 && nVertices % 3 == 0, "mvrt_svo_build: need 3*k vertices" );
+	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
+	hipStream_t st = (hipStream_t)stream;
+	svo->cleanUp(); // :53
+	SvoBuildResult r;
+	memset( &r, 0, sizeof( r ) );
+	if( svoBuildFromTriangles( verticesHost, vcolorsHost, vemissionsHost, nVertices, mk3( origin[0], origin[1], origin[2] ), dps, gridRes, st, &r ) ) return 1;
+	REQUIRE( r.nNodes < 0xFFFFFFu, "octree has %u nodes; embedded masks need fewer than 0xFFFFFF (IntersectorOctreeGPU.hpp:231)", r.nNodes );
+	svo->nodes = r.nodes;
+	svo->masks = r.masks;
+	svo->attrs = r.attrs;
+	svo->morton = r.morton;
+	svo->info.numberOfNodes = r.nNodes;
+	svo->info.numberOfVoxels = r.nVoxels;
+	svo->info.hasEmission = r.hasEmission;
+	svo->info.embeddedMask = 1;
+	svo->info.totalDumpedVoxels = r.totalDumped;
+	setBounds( svo, origin, dps, gridRes );
+	MVRT_HIP( hipMemcpy( &svo->rootMask, svo->masks + ( r.nNodes - 1 ), 1, hipMemcpyDeviceToHost ) );
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info )
+{
+	REQUIRE( svo && info, "null argument" );
+	*info = svo->info;
+	return 0;
+}
+MVRT_EXPORT int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale )
+{
+	REQUIRE( svo, "null argument" );
+	svo->info.emissionScale = scale;
+	return 0;
+}
+MVRT_EXPORT int mvrt_svo_download( const mvrt_svo* svo, void* nodes68Host, void* attribs8Host, uint64_t* mortonHost, void* stream )
+{
+	REQUIRE( svo && svo->nodes, "no octree" );
+	hipStream_t st = (hipStream_t)stream;
+	if( nodes68Host )
+	{
+		DevBuf raw;
+		if( raw.alloc( (uint64_t)svo->info.numberOfNodes * 68 ) ) return 1;
+		if( launchNodesTo68( svo->nodes, svo->masks, svo->info.numberOfNodes, raw.as<uint8_t>(), st ) ) return 1;
+		MVRT_HIP( hipMemcpyAsync( nodes68Host, raw.p, raw.bytes, hipMemcpyDeviceToHost, st ) );
+		MVRT_HIP( hipStreamSynchronize( st ) );
+	}
+	if( attribs8Host ) MVRT_HIP( hipMemcpyAsync( attribs8Host, svo->attrs, (uint64_t)svo->info.numberOfVoxels * 8, hipMemcpyDeviceToHost, st ) );
+	if( mortonHost )
+	{
+		REQUIRE( svo->morton, "morton codes are only kept by mvrt_svo_build" );
+		MVRT_HIP( hipMemcpyAsync( mortonHost, svo->morton, (uint64_t)svo->info.numberOfVoxels * 8, hipMemcpyDeviceToHost, st ) );
+	}
+	MVRT_HIP( hipStreamSynchronize( st ) );
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_trace_batch( const mvrt_svo* svo, uint64_t n, const float* roxDev, const float* royDev, const float* rozDev, const float* rdxDev, const float* rdyDev,
+								  const float* rdzDev, const uint8_t* isShadowDev, float* tDev, int32_t* nMajorDev, uint32_t* vIndexDev, uint32_t* descentsDev, void* stream )
+{
+	REQUIRE( svo && svo->nodes, "mvrt_trace_batch: no octree (build or upload first)" );
+	REQUIRE( tDev, "mvrt_trace_batch: t output is required" );
+	return launchTraceBatch( svo->dev(), n, roxDev, royDev, rozDev, rdxDev, rdyDev, rdzDev, isShadowDev, tDev, nMajorDev, vIndexDev, descentsDev, (hipStream_t)stream );
+}
+
+MVRT_EXPORT int mvrt_trace_batch_host( const mvrt_svo* svo, uint64_t n, const float* roHost, const float* rdHost, const uint8_t* isShadowHost, float* tHost,
+									   int32_t* nMajorHost, uint32_t* vIndexHost, uint32_t* descentsHost )
+{
+	REQUIRE( svo && svo->nodes, "mvrt_trace_batch_host: no octree" );
+	if( n == 0 ) return 0;
+	std::vector<float> soa( n * 6 );
+	for( uint64_t i = 0; i < n; i++ )
+		for( int k = 0; k < 3; k++ )
+		{
+			soa[k * n + i] = roHost[i * 3 + k];
+			soa[( 3 + k ) * n + i] = rdHost[i * 3 + k];
+		}
+	DevBuf in, sh, t, nm, vi, de;
+	if( in.alloc( n * 24 ) || t.alloc( n * 4 ) || nm.alloc( n * 4 ) || vi.alloc( n * 4 ) || de.alloc( n * 4 ) ) return 1;
+	MVRT_HIP( hipMemcpy( in.p, soa.data(), n * 24, hipMemcpyHostToDevice ) );
+	if( isShadowHost )
+	{
+		if( sh.alloc( n ) ) return 1;
+		MVRT_HIP( hipMemcpy( sh.p, isShadowHost, n, hipMemcpyHostToDevice ) );
+	}
+	const float* b = in.as<float>();
+	if( launchTraceBatch( svo->dev(), n, b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, isShadowHost ? sh.as<uint8_t>() : nullptr, t.as<float>(), nm.as<int32_t>(),
+						  vi.as<uint32_t>(), de.as<uint32_t>(), 0 ) )
+		return 1;
+	MVRT_HIP( hipDeviceSynchronize() );
+	MVRT_HIP( hipMemcpy( tHost, t.p, n * 4, hipMemcpyDeviceToHost ) );
+	if( nMajorHost ) MVRT_HIP( hipMemcpy( nMajorHost, nm.p, n * 4, hipMemcpyDeviceToHost ) );
+	if( vIndexHost ) MVRT_HIP( hipMemcpy( vIndexHost, vi.p, n * 4, hipMemcpyDeviceToHost ) );
+	if( descentsHost ) MVRT_HIP( hipMemcpy( descentsHost, de.p, n * 4, hipMemcpyDeviceToHost ) );
+	return 0;
+}
+
+static CameraPinhole cameraFrom15( const float c[15] )
+{
+	CameraPinhole cam;
+	memcpy( &cam, c, sizeof( cam ) );
+	return cam;
+}
+
+MVRT_EXPORT int mvrt_render_primary( const mvrt_svo* svo, const float camera[15], int width, int height, int showVertexColor, uint8_t* rgbaDev, float* tDev,
+									 int32_t* nMajorDev, uint32_t* vIndexDev, uint32_t* descentsDev, void* stream )
+{
+	REQUIRE( svo && svo->nodes, "mvrt_render_primary: no octree" );
+	REQUIRE( width > 0 && height > 0, "bad resolution %dx%d", width, height );
+	return launchRenderPrimary( svo->dev(), cameraFrom15( camera ), width, height, showVertexColor, (uchar4*)rgbaDev, tDev, nMajorDev, vIndexDev, descentsDev,
+								(hipStream_t)stream );
+}
+
+// CameraPinhole::initFromPerspective, renderCommon.hpp:21-35 (glm column-major matrices)
+MVRT_EXPORT int mvrt_camera_from_matrices( const float view[16], const float proj[16], float focus, float lensR, float cameraOut[15] )
+{
+	f3 r0 = mk3( view[0], view[4], view[8] ); // rows of mat3(view) = columns of its transpose
+	f3 r1 = mk3( view[1], view[5], view[9] );
+	f3 r2 = mk3( view[2], view[6], view[10] );
+	f3 v = mk3( view[12], view[13], view[14] );
+	f3 m = mk3( r0.x * v.x + r1.x * v.y + r2.x * v.z, r0.y * v.x + r1.y * v.y + r2.y * v.z, r0.z * v.x + r1.z * v.y + r2.z * v.z );
+	CameraPinhole c;
+	c.front = mk3( -r2.x, -r2.y, -r2.z );
+	c.up = r1;
+	c.right = r0;
+	c.o = mk3( -m.x, -m.y, -m.z );
+	c.tanHthetaY = 1.0f / proj[5];
+	c.lensR = lensR;
+	c.focus = focus;
+	memcpy( cameraOut, &c, sizeof( c ) );
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_compact_indices( const uint8_t* keepDev, uint64_t n, uint32_t* dstIndexDev, uint32_t* keptDev, void* stream )
+{
+	if( n == 0 )
+	{
+		if( keptDev ) MVRT_HIP( hipMemsetAsync( keptDev, 0, 4, (hipStream_t)stream ) );
+		return 0;
+	}
+	DevBuf scratch;
+	if( scratch.alloc( ( n / 256 + 2 ) * 4 ) ) return 1;
+	if( launchCompactIndices( keepDev, n, dstIndexDev, keptDev, scratch.as<uint32_t>(), (hipStream_t)stream ) ) return 1;
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) ); // scratch is freed on return
+	return 0;
+}
+
+// ---- PMJ02 table (host), pmjSampler.hpp:14-58,114-144 -----------------------------------------------------
+namespace
+{
+struct PCG32 // renderCommon.hpp:86-110
+{
+	uint64_t state, inc;
+	void setup( uint64_t seed, uint64_t stream )
+	{
+		state = 0;
+		inc = stream * 2 + 1;
+		nextU32();
+		state += seed;
+		nextU32();
+	}
+	uint32_t nextU32()
+	{
+		uint64_t old = state;
+		state = old * 6364136223846793005ULL + inc;
+		uint32_t xs = (uint32_t)( ( ( old >> 18u ) ^ old ) >> 27u );
+		uint32_t rot = (uint32_t)( old >> 59u );
+		return ( xs >> rot ) | ( xs << ( ( -rot ) & 31 ) );
+	}
+};
+inline float uniformf( uint32_t x ) { return mvrt_u2f( ( x >> 9 ) | 0x3f800000u ) - 1.0f; } // :112-117
+
+// Helmer's stochastic generation of a pmj02 sequence; xi0 is drawn before xi1 (see DESIGN.md "PMJ order")
+void pmj02Sequence( int numSamples, float* samples, PCG32& rng )
+{
+	static const uint32_t xors[2][32] = {
+		{ 0x0, 0x0, 0x2, 0x6, 0x6, 0xe, 0x36, 0x4e, 0x16, 0x2e, 0x276, 0x6ce, 0x716, 0xc2e, 0x3076, 0x40ce, 0x116, 0x22e, 0x20676, 0x60ece, 0x61716,
+		  0xe2c2e, 0x367076, 0x4ec0ce, 0x170116, 0x2c022e, 0x2700676, 0x6c00ece, 0x7001716, 0xc002c2e, 0x30007076, 0x4000c0ce },
+		{ 0x0, 0x1, 0x3, 0x3, 0x7, 0x1b, 0x27, 0xb, 0x17, 0x13b, 0x367, 0x38b, 0x617, 0x183b, 0x2067, 0x8b, 0x117, 0x1033b, 0x30767, 0x30b8b,
+		  0x71617, 0x1b383b, 0x276067, 0xb808b, 0x160117, 0x138033b, 0x3600767, 0x3800b8b, 0x6001617, 0x1800383b, 0x20006067, 0x808b } };
+	samples[0] = uniformf( rng.nextU32() );
+	samples[1] = uniformf( rng.nextU32() );
+	for( int logN = 0; ( 1 << logN ) < numSamples; logN++ )
+	{
+		const int prevLen = 1 << logN;
+		const int nStrata = prevLen * 2;
+		const float iStrata = 1.0f / nStrata;
+		for( int i = 0; i < prevLen && ( prevLen + i ) < numSamples; i++ )
+		{
+			const int xStratum = ( (int)( samples[( i ^ xors[0][logN] ) * 2] * nStrata ) ) ^ 1;
+			const int yStratum = ( (int)( samples[( i ^ xors[1][logN] ) * 2 + 1] * nStrata ) ) ^ 1;
+			const float xi0 = uniformf( rng.nextU32() );
+			const float xi1 = uniformf( rng.nextU32() );
+			samples[( prevLen + i ) * 2] = ( xi0 + xStratum ) * iStrata;
+			samples[( prevLen + i ) * 2 + 1] = ( xi1 + yStratum ) * iStrata;
+		}
+	}
+}
+
+// Radiance RGBE reader: header lines, blank line, "-Y h +X w", then flat or new-RLE scanlines.
+int loadRgbe( const char* path, std::vector<float>& rgba, int* w, int* h )
+{
+	FILE* fp = fopen( path, "rb" );
+	REQUIRE( fp, "cannot open %s", path );
+	std::vector<uint8_t> d;
+	uint8_t tmp[65536];
+	size_t got;
+	while( ( got = fread( tmp, 1, sizeof( tmp ), fp ) ) > 0 ) d.insert( d.end(), tmp, tmp + got );
+	fclose( fp );
+	size_t pos = 0;
+	bool blank = false;
+	*w = *h = 0;
+	while( pos < d.size() )
+	{
+		size_t e = pos;
+		while( e < d.size() && d[e] != '\n' ) e++;
+		std::string line( (const char*)d.data() + pos, e - pos );
+		pos = e + 1;
+		if( !blank )
+		{
+			if( line.empty() ) blank = true;
+			continue;
+		}
+		REQUIRE( sscanf( line.c_str(), "-Y %d +X %d", h, w ) == 2, "%s: unsupported resolution line '%s'", path, line.c_str() );
+		break;
+	}
+	REQUIRE( *w > 0 && *h > 0, "%s: not a Radiance .hdr file", path );
+	const int W = *w, H = *h;
+	rgba.resize( (size_t)W * H * 4 );
+	std::vector<uint8_t> scan( (size_t)W * 4 );
+	for( int y = 0; y < H; y++ )
+	{
+		if( pos + 4 <= d.size() && W >= 8 && W < 32768 && d[pos] == 2 && d[pos + 1] == 2 && ( d[pos + 2] & 0x80 ) == 0 && ( ( d[pos + 2] << 8 ) | d[pos + 3] ) == W )
+		{
+			pos += 4;
+			for( int c = 0; c < 4; c++ )
+			{
+				int x = 0;
+				while( x < W )
+				{
+					REQUIRE( pos < d.size(), "%s: truncated RLE data", path );
+					int count = d[pos++];
+					if( count > 128 )
+					{
+						count -= 128;
+						REQUIRE( pos < d.size() && x + count <= W, "%s: bad RLE run", path );
+						uint8_t v = d[pos++];
+						for( int k = 0; k < count; k++ ) scan[( x++ ) * 4 + c] = v;
+					}
+					else
+					{
+						REQUIRE( pos + count <= d.size() && x + count <= W, "%s: bad RLE literal", path );
+						for( int k = 0; k < count; k++ ) scan[( x++ ) * 4 + c] = d[pos++];
+					}
+				}
+			}
+		}
+		else
+		{
+			REQUIRE( pos + (size_t)W * 4 <= d.size(), "%s: truncated pixel data", path );
+			memcpy( scan.data(), d.data() + pos, (size_t)W * 4 );
+			pos += (size_t)W * 4;
+		}
+		for( int x = 0; x < W; x++ )
+		{
+			const uint8_t* p = &scan[(size_t)x * 4];
+			float* o = &rgba[( (size_t)y * W + x ) * 4];
+			if( p[3] )
+			{
+				float f = mvrt_u2f( (uint32_t)( (int)p[3] - 136 + 127 ) << 23 ); // 2^(E-136), E >= 10 keeps it normal
+				if( (int)p[3] - 136 + 127 <= 0 ) f = 0.0f;
+				o[0] = p[0] * f;
+				o[1] = p[1] * f;
+				o[2] = p[2] * f;
+			}
+			else
+			{
+				o[0] = o[1] = o[2] = 0.0f;
+			}
+			o[3] = 1.0f;
+		}
+	}
+	return 0;
+}
+} // namespace
+
+// ---- PathTracer ---------------------------------------------------------------------------------------------
+struct EventProfiler : PtProfiler
+{
+	struct Rec
+	{
+		hipEvent_t a, b;
+		int cls;
+	};
+	std::vector<Rec> recs;
+	std::vector<hipEvent_t> pool;
+	double ms[3] = { 0, 0, 0 };
+	uint64_t traceLaunches = 0;
+	hipEvent_t get()
+	{
+		if( !pool.empty() )
+		{
+			hipEvent_t e = pool.back();
+			pool.pop_back();
+			return e;
+		}
+		hipEvent_t e;
+		(void)hipEventCreate( &e );
+		return e;
+	}
+	void begin( int cls, hipStream_t s ) override
+	{
+		Rec r;
+		r.a = get();
+		r.b = get();
+		r.cls = cls;
+		(void)hipEventRecord( r.a, s );
+		recs.push_back( r );
+	}
+	void end( hipStream_t s ) override { (void)hipEventRecord( recs.back().b, s ); }
+	void collect() // caller has synchronised the stream
+	{
+		for( Rec& r : recs )
+		{
+			float t = 0.0f;
+			if( hipEventElapsedTime( &t, r.a, r.b ) == hipSuccess ) ms[r.cls] += t;
+			if( r.cls == MVRT_K_TRACE ) traceLaunches++;
+			pool.push_back( r.a );
+			pool.push_back( r.b );
+		}
+		recs.clear();
+	}
+	~EventProfiler()
+	{
+		collect();
+		for( hipEvent_t e : pool ) (void)hipEventDestroy( e );
+	}
+};
+
+struct mvrt_pt
+{
+	mvrt_svo* intersector = nullptr; // m_intersectorOctreeGPU
+	DevBuf pmj;						 // m_pmj
+	// m_hdri
+	DevBuf hdriPixels, hdriPrimary, hdriSat[7];
+	HdriDev hdri;
+	// frame buffers
+	DevBuf fbF32, fbU8; // m_frameBufferF32 / m_frameBufferU8
+	int width = 0, height = 0, steps = 0;
+	int tileIndex = 0, tileCount = 1;
+	uint64_t ownedPixels = 0, validOwnedPixels = 0;
+	// wavefront work buffers
+	DevBuf work;
+	PtBuffers buf;
+	bool setupDone = false;
+	bool profiling = false;
+	EventProfiler prof;
+	int numCUs = 0;
+	mvrt_pt()
+	{
+		memset( &hdri, 0, sizeof( hdri ) );
+		hdri.scale = 1.75f; // renderCommon.hpp:480
+		memset( &buf, 0, sizeof( buf ) );
+	}
+};
+
+MVRT_EXPORT int mvrt_pt_create( mvrt_pt** out )
+{
+	mvrt_pt* pt = new mvrt_pt();
+	pt->intersector = new mvrt_svo();
+	*out = pt;
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_destroy( mvrt_pt* pt )
+{
+	if( pt )
+	{
+		mvrt_svo_destroy( pt->intersector );
+		delete pt;
+	}
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_setup( mvrt_pt* pt, void* stream )
+{
+	REQUIRE( pt, "null argument" );
+	// PMJSampler::setup, pmjSampler.hpp:114-144
+	std::vector<float> samples( (size_t)2 * MVRT_PMJ_LENGTH * MVRT_PMJ_NSEQ );
+	PCG32 rng;
+	rng.setup( 0, 2525 );
+	for( int i = 0; i < MVRT_PMJ_NSEQ; i++ ) pmj02Sequence( MVRT_PMJ_LENGTH, samples.data() + (size_t)2 * MVRT_PMJ_LENGTH * i, rng );
+	if( pt->pmj.alloc( samples.size() * 4 ) ) return 1;
+	MVRT_HIP( hipMemcpyAsync( pt->pmj.p, samples.data(), samples.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream ) );
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+	int dev = 0;
+	MVRT_HIP( hipGetDevice( &dev ) );
+	hipDeviceProp_t p;
+	MVRT_HIP( hipGetDeviceProperties( &p, dev ) );
+	pt->numCUs = p.multiProcessorCount;
+	pt->setupDone = true;
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_pt_set_tile( mvrt_pt* pt, int tileIndex, int tileCount )
+{
+	REQUIRE( pt && tileCount >= 1 && tileIndex >= 0 && tileIndex < tileCount, "bad tile %d of %d", tileIndex, tileCount );
+	pt->tileIndex = tileIndex;
+	pt->tileCount = tileCount;
+	pt->width = pt->height = 0; // force re-allocation on the next resize
+	pt->fbF32.release();
+	return 0;
+}
+MVRT_EXPORT uint64_t mvrt_pt_owned_pixels( const mvrt_pt* pt ) { return pt ? pt->ownedPixels : 0; }
+
+static int allocWork( mvrt_pt* pt )
+{
+	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP;
+	const uint64_t nBlocks = cap / 256 + 2;
+	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays, 4 bytes each;
+	// 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
+	const uint64_t words = cap * ( 32 + 6 + 3 + 3 );
+	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 16 * 8 + 64 * 256;
+	if( pt->work.alloc( bytes ) ) return 1;
+	uint8_t* base = (uint8_t*)pt->work.p;
+	uint64_t off = 0;
+	auto take = [&]( uint64_t b ) {
+		void* r = base + off;
+		off += ( b + 255 ) & ~(uint64_t)255;
+		return r;
+	};
+	PtBuffers& b = pt->buf;
+	for( int s = 0; s < 2; s++ )
+	{
+		PathSet& ps = b.set[s];
+		ps.task = (uint32_t*)take( cap * 4 );
+		float** f[] = { &ps.rox, &ps.roy, &ps.roz, &ps.rdx, &ps.rdy, &ps.rdz, &ps.Tx, &ps.Ty, &ps.Tz, &ps.Lx, &ps.Ly, &ps.Lz, &ps.nx, &ps.ny, &ps.nz };
+		for( float** q : f ) *q = (float*)take( cap * 4 );
+	}
+	float** d[] = { &b.sx, &b.sy, &b.sz, &b.ex, &b.ey, &b.ez, &b.hitT, &b.Lsx, &b.Lsy, &b.Lsz };
+	for( float** q : d ) *q = (float*)take( cap * 4 );
+	b.hitV = (uint32_t*)take( cap * 4 );
+	b.hitEV = (uint32_t*)take( cap * 4 );
+	b.hitN = (uint8_t*)take( cap );
+	b.hitS = (uint8_t*)take( cap );
+	b.hitE = (uint8_t*)take( cap );
+	b.blockCount = (uint32_t*)take( nBlocks * 4 );
+	b.liveCount = (uint32_t*)take( 64 * 4 );
+	b.stats = (unsigned long long*)take( 16 * 8 );
+	b.cap = cap;
+	MVRT_HIP( hipMemset( b.liveCount, 0, 64 * 4 ) );
+	MVRT_HIP( hipMemset( b.stats, 0, 16 * 8 ) );
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_pt_clear_framebuffer( mvrt_pt* pt, void* stream )
+{
+	REQUIRE( pt && pt->fbF32.p, "no frame buffer" );
+	pt->steps = 0; // PathTracer.hpp:100
+	MVRT_HIP( hipMemsetAsync( pt->fbF32.p, 0, pt->fbF32.bytes, (hipStream_t)stream ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_resize_framebuffer_if_needed( mvrt_pt* pt, void* stream, int width, int height )
+{
+	REQUIRE( pt && width > 0 && height > 0, "bad resolution %dx%d", width, height );
+	if( pt->fbF32.p && pt->width == width && pt->height == height ) return 0;
+	const uint64_t nPix = (uint64_t)width * height;
+	const uint64_t nBlocks = ( nPix + MVRT_TILE_PIXELS - 1 ) / MVRT_TILE_PIXELS;
+	// blocks b with b % tileCount == tileIndex
+	const uint64_t myBlocks = nBlocks > (uint64_t)pt->tileIndex ? ( nBlocks - pt->tileIndex + pt->tileCount - 1 ) / pt->tileCount : 0;
+	// every rank pads to the same count so an all-gather of equal chunks works
+	const uint64_t maxBlocks = ( nBlocks + pt->tileCount - 1 ) / pt->tileCount;
+	pt->ownedPixels = maxBlocks * MVRT_TILE_PIXELS;
+	uint64_t valid = myBlocks * MVRT_TILE_PIXELS;
+	if( myBlocks > 0 )
+	{
+		const uint64_t lastGlobalBlock = ( myBlocks - 1 ) * pt->tileCount + pt->tileIndex;
+		const uint64_t endPix = ( lastGlobalBlock + 1 ) * MVRT_TILE_PIXELS;
+		if( endPix > nPix ) valid -= endPix - nPix;
+	}
+	pt->validOwnedPixels = valid;
+	pt->width = width;
+	pt->height = height;
+	if( pt->fbF32.alloc( pt->ownedPixels * sizeof( float4 ) ) ) return 1;
+	if( pt->fbU8.alloc( pt->ownedPixels * sizeof( uchar4 ) ) ) return 1;
+	if( allocWork( pt ) ) return 1;
+	return mvrt_pt_clear_framebuffer( pt, stream ); // :88
+}
+
+MVRT_EXPORT int mvrt_pt_load_hdri( mvrt_pt* pt, void* stream, const float* rgbaHost, int width, int height, const float* rgbaPrimaryHost, int widthPrimary,
+								   int heightPrimary )
+{
+	REQUIRE( pt && rgbaHost && width > 0 && height > 0, "mvrt_pt_load_hdri: bad image" );
+	hipStream_t st = (hipStream_t)stream;
+	const uint64_t n = (uint64_t)width * height;
+	if( pt->hdriPixels.alloc( n * 16 ) ) return 1;
+	MVRT_HIP( hipMemcpyAsync( pt->hdriPixels.p, rgbaHost, n * 16, hipMemcpyHostToDevice, st ) );
+	DevBuf satF64;
+	if( satF64.alloc( n * 8 ) ) return 1;
+	// renderCommon.hpp:243-311: uniform table, then one cosine-weighted table per axis
+	const f3 axes[6] = { mk3( 1, 0, 0 ), mk3( -1, 0, 0 ), mk3( 0, 1, 0 ), mk3( 0, -1, 0 ), mk3( 0, 0, 1 ), mk3( 0, 0, -1 ) };
+	for( int i = 0; i < 7; i++ )
+	{
+		if( pt->hdriSat[i].alloc( n * 4 ) ) return 1;
+		if( launchHdriSat( pt->hdriPixels.as<float4>(), width, height, satF64.as<double>(), pt->hdriSat[i].as<uint32_t>(), i > 0, i > 0 ? axes[i - 1] : mk3( 0, 0, 0 ), st ) )
+			return 1;
+	}
+	pt->hdri.pixels = pt->hdriPixels.as<float4>();
+	pt->hdri.sat = pt->hdriSat[0].as<uint32_t>();
+	for( int i = 0; i < 6; i++ ) pt->hdri.sats[i] = pt->hdriSat[i + 1].as<uint32_t>();
+	pt->hdri.width = width;
+	pt->hdri.height = height;
+	if( rgbaPrimaryHost ) // HDRI::loadPrimary, :315-326
+	{
+		const uint64_t np = (uint64_t)widthPrimary * heightPrimary;
+		if( pt->hdriPrimary.alloc( np * 16 ) ) return 1;
+		MVRT_HIP( hipMemcpyAsync( pt->hdriPrimary.p, rgbaPrimaryHost, np * 16, hipMemcpyHostToDevice, st ) );
+		pt->hdri.pixelsPrimary = pt->hdriPrimary.as<float4>();
+		pt->hdri.widthPrimary = widthPrimary;
+		pt->hdri.heightPrimary = heightPrimary;
+	}
+	else
+	{
+		pt->hdriPrimary.release();
+		pt->hdri.pixelsPrimary = nullptr;
+		pt->hdri.widthPrimary = width; // see mvrt.h: the reference would index with 0x0 here
+		pt->hdri.heightPrimary = height;
+	}
+	MVRT_HIP( hipStreamSynchronize( st ) ); // :313
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_load_hdri_file( mvrt_pt* pt, void* stream, const char* file, const char* filePrimary )
+{
+	std::vector<float> a, b;
+	int w = 0, h = 0, wp = 0, hp = 0;
+	if( loadRgbe( file, a, &w, &h ) ) return 1;
+	if( filePrimary && loadRgbe( filePrimary, b, &wp, &hp ) ) return 1;
+	return mvrt_pt_load_hdri( pt, stream, a.data(), w, h, filePrimary ? b.data() : nullptr, wp, hp );
+}
+MVRT_EXPORT int mvrt_pt_download_hdri_sat( mvrt_pt* pt, int which, uint32_t* satHost )
+{
+	REQUIRE( pt && which >= 0 && which < 7 && pt->hdriSat[which].p, "no such HDRI table" );
+	MVRT_HIP( hipMemcpy( satHost, pt->hdriSat[which].p, pt->hdriSat[which].bytes, hipMemcpyDeviceToHost ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_set_hdri_scale( mvrt_pt* pt, float scale )
+{
+	REQUIRE( pt, "null argument" );
+	pt->hdri.scale = scale;
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_update_scene( mvrt_pt* pt, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
+									  const float origin[3], float dps, int gridRes )
+{
+	REQUIRE( pt, "null argument" );
+	return mvrt_svo_build( pt->intersector, verticesHost, vcolorsHost, vemissionsHost, nVertices, stream, origin, dps, gridRes );
+}
+MVRT_EXPORT mvrt_svo* mvrt_pt_intersector( mvrt_pt* pt ) { return pt ? pt->intersector : nullptr; }
+
+MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] )
+{
+	REQUIRE( pt && pt->setupDone, "mvrt_pt_step: call mvrt_pt_setup first" );
+	REQUIRE( pt->intersector->nodes, "mvrt_pt_step: no scene (updateScene / upload first)" );
+	REQUIRE( pt->fbF32.p, "mvrt_pt_step: no frame buffer (resizeFrameBufferIfNeeded first)" );
+	REQUIRE( !( 0.0f < pt->hdri.scale ) || pt->hdri.pixels, "mvrt_pt_step: HDRI enabled (scale > 0) but none loaded" );
+	PtFrame f;
+	f.width = pt->width;
+	f.height = pt->height;
+	f.tileIndex = pt->tileIndex;
+	f.tileCount = pt->tileCount;
+	f.ownedPixels = pt->ownedPixels;
+	f.validOwnedPixels = pt->validOwnedPixels;
+	f.iteration = pt->steps++; // PathTracer.hpp:159
+	int rc = launchPtStep( pt->intersector->dev(), pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, pt->buf, pt->fbF32.as<float4>(), pt->numCUs,
+						   pt->profiling ? &pt->prof : nullptr, (hipStream_t)stream );
+	if( rc ) return rc;
+	if( pt->profiling )
+	{
+		MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+		pt->prof.collect();
+	}
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], const float proj[16], float focus, float lensR )
+{
+	float cam[15];
+	mvrt_camera_from_matrices( view, proj, focus, lensR, cam );
+	return mvrt_pt_step( pt, stream, cam );
+}
+MVRT_EXPORT int mvrt_pt_resolve( mvrt_pt* pt, void* stream )
+{
+	REQUIRE( pt && pt->fbF32.p, "no frame buffer" );
+	return launchResolve( pt->fbF32.as<float4>(), pt->validOwnedPixels, pt->fbU8.as<uchar4>(), (hipStream_t)stream );
+}
+MVRT_EXPORT int mvrt_pt_to_image_async( mvrt_pt* pt, void* stream, uint8_t* rgbaHost )
+{
+	if( mvrt_pt_resolve( pt, stream ) ) return 1;
+	MVRT_HIP( hipMemcpyAsync( rgbaHost, pt->fbU8.p, pt->validOwnedPixels * 4, hipMemcpyDeviceToHost, (hipStream_t)stream ) );
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_get_steps( const mvrt_pt* pt ) { return pt ? pt->steps : 0; }
+MVRT_EXPORT uint64_t mvrt_pt_get_number_of_voxels( const mvrt_pt* pt ) { return pt ? pt->intersector->info.numberOfVoxels : 0; }
+MVRT_EXPORT uint64_t mvrt_pt_get_octree_bytes( const mvrt_pt* pt ) { return pt ? (uint64_t)pt->intersector->info.numberOfNodes * 68 : 0; }
+MVRT_EXPORT int mvrt_pt_read_framebuffer( mvrt_pt* pt, void* stream, float* rgbaHost )
+{
+	REQUIRE( pt && pt->fbF32.p, "no frame buffer" );
+	MVRT_HIP( hipMemcpyAsync( rgbaHost, pt->fbF32.p, pt->ownedPixels * 16, hipMemcpyDeviceToHost, (hipStream_t)stream ) );
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+	return 0;
+}
+MVRT_EXPORT float* mvrt_pt_framebuffer_dev( mvrt_pt* pt ) { return pt ? pt->fbF32.as<float>() : nullptr; }
+MVRT_EXPORT uint8_t* mvrt_pt_framebuffer_u8_dev( mvrt_pt* pt ) { return pt ? pt->fbU8.as<uint8_t>() : nullptr; }
+MVRT_EXPORT const float* mvrt_pt_sample_radiance_dev( mvrt_pt* pt ) { return pt ? pt->buf.Lsx : nullptr; }
+
+MVRT_EXPORT int mvrt_pt_assemble_tiles( const float* gatheredDev, int tileCount, uint64_t rankStridePixels, int width, int height, float* frameDev, void* stream )
+{
+	REQUIRE( gatheredDev && frameDev && tileCount >= 1, "bad arguments" );
+	return launchAssembleTiles( (const float4*)gatheredDev, tileCount, rankStridePixels, width, height, (float4*)frameDev, (hipStream_t)stream );
+}
+MVRT_EXPORT int mvrt_resolve_buffer( const float* rgbaF32Dev, uint64_t nPixels, uint8_t* rgbaU8Dev, void* stream )
+{
+	return launchResolve( (const float4*)rgbaF32Dev, nPixels, (uchar4*)rgbaU8Dev, (hipStream_t)stream );
+}
+
+MVRT_EXPORT int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled )
+{
+	REQUIRE( pt, "null argument" );
+	pt->profiling = enabled != 0;
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_reset_stats( mvrt_pt* pt )
+{
+	REQUIRE( pt, "null argument" );
+	if( pt->buf.stats ) MVRT_HIP( hipMemset( pt->buf.stats, 0, 16 * 8 ) );
+	pt->prof.collect();
+	pt->prof.ms[0] = pt->prof.ms[1] = pt->prof.ms[2] = 0.0;
+	pt->prof.traceLaunches = 0;
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out )
+{
+	REQUIRE( pt && out, "null argument" );
+	memset( out, 0, sizeof( *out ) );
+	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
+	if( pt->buf.stats )
+	{
+		unsigned long long s[6];
+		MVRT_HIP( hipMemcpy( s, pt->buf.stats, sizeof( s ), hipMemcpyDeviceToHost ) );
+		out->rays = s[0];
+		out->shadowRays = s[1];
+		out->descents = s[2];
+		out->shadowDescents = s[3];
+		out->hits = s[4];
+		out->samples = s[5];
+	}
+	pt->prof.collect();
+	out->traceLaunches = pt->prof.traceLaunches;
+	out->traceKernelMs = pt->prof.ms[MVRT_K_TRACE];
+	out->shadeKernelMs = pt->prof.ms[MVRT_K_SHADE];
+	out->totalKernelMs = pt->prof.ms[0] + pt->prof.ms[1] + pt->prof.ms[2];
+	return 0;
+}

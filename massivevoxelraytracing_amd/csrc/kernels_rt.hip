@@ -1,0 +1,702 @@
+// kernels_rt.hip -- the hot path: octree traversal, primary cast, wavefront path tracer with stable
+// live-path compaction.  Hand-written for gfx950 (wave64, LDS stacks, SoA buffers).
+//
+// Reference semantics (what each kernel must reproduce): /root/reference/voxKernel.cu:437-483 (render),
+// :610-777 (renderPT), voxCommon.hpp:231-423 (traversal), StreamCompaction.hpp:87-184 (stable compaction).
+#include "launch.h"
+#include "traverse.h"
+
+#define WAVE 64
+#define TRACE_BLOCK 64 // one wavefront per workgroup: no barriers, LDS granule = one wave's stack
+
+MVRT_DI uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi( ~0u, __builtin_amdgcn_mbcnt_lo( ~0u, 0u ) ); }
+
+MVRT_DI unsigned long long waveSum( unsigned long long v )
+{
+	for( int o = 32; o > 0; o >>= 1 ) v += __shfl_down( v, o, WAVE );
+	return v;
+}
+
+// =====================================================================================================
+// mvrt_trace_batch: host-callable batch form of IntersectorOctreeGPU::intersect
+// =====================================================================================================
+__global__ void __launch_bounds__( TRACE_BLOCK ) kTraceBatch( SvoDev svo, uint64_t n, const float* __restrict__ rox, const float* __restrict__ roy,
+															   const float* __restrict__ roz, const float* __restrict__ rdx, const float* __restrict__ rdy,
+															   const float* __restrict__ rdz, const uint8_t* __restrict__ isShadow, float* __restrict__ tOut,
+															   int32_t* __restrict__ nMajorOut, uint32_t* __restrict__ vIndexOut, uint32_t* __restrict__ descentsOut )
+{
+	extern __shared__ uint32_t lds[];
+	const uint32_t lane = threadIdx.x;
+	for( uint64_t base = (uint64_t)blockIdx.x * TRACE_BLOCK; base < n; base += (uint64_t)gridDim.x * TRACE_BLOCK )
+	{
+		uint64_t i = base + lane;
+		if( i < n )
+		{
+			f3 ro = mk3( rox[i], roy[i], roz[i] );
+			f3 rd = mk3( rdx[i], rdy[i], rdz[i] );
+			bool sh = isShadow ? isShadow[i] != 0 : false;
+			TraceResult r = traceRay<true>( svo, ro, rd, sh, lds, TRACE_BLOCK, lane );
+			tOut[i] = r.t;
+			if( nMajorOut ) nMajorOut[i] = r.nMajor;
+			if( vIndexOut ) vIndexOut[i] = r.vIndex;
+			if( descentsOut ) descentsOut[i] = r.descents;
+		}
+	}
+}
+
+static size_t traceLdsBytes( const SvoDev& svo, int block )
+{
+	uint32_t slots = svo.levels < 1 ? 1 : svo.levels;
+	return (size_t)slots * MVRT_STACK_FIELDS * block * sizeof( uint32_t );
+}
+
+static int persistentGrid( uint64_t items, int block, int numCUs, int blocksPerCU )
+{
+	uint64_t need = ( items + block - 1 ) / block;
+	uint64_t cap = (uint64_t)numCUs * blocksPerCU;
+	if( need < 1 ) need = 1;
+	return (int)( need < cap ? need : cap );
+}
+
+static int g_numCUs = 0;
+static int numCUs()
+{
+	if( g_numCUs == 0 )
+	{
+		int dev = 0;
+		hipDeviceProp_t p;
+		if( hipGetDevice( &dev ) == hipSuccess && hipGetDeviceProperties( &p, dev ) == hipSuccess ) g_numCUs = p.multiProcessorCount;
+		if( g_numCUs <= 0 ) g_numCUs = 256;
+	}
+	return g_numCUs;
+}
+
+template <class K>
+static int allowLds( K kernel, size_t bytes )
+{
+	if( bytes > 64 * 1024 )
+	{
+		MVRT_HIP( hipFuncSetAttribute( (const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes ) );
+	}
+	return 0;
+}
+
+int launchTraceBatch( const SvoDev& svo, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy, const float* rdz,
+					  const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
+{
+	if( n == 0 ) return 0;
+	size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
+	if( allowLds( kTraceBatch, lds ) ) return 1;
+	int grid = persistentGrid( n, TRACE_BLOCK, numCUs(), 32 );
+	hipLaunchKernelGGL( kTraceBatch, dim3( grid ), dim3( TRACE_BLOCK ), lds, stream, svo, n, rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, vIndex, descents );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
+// =====================================================================================================
+// mvrt_render_primary: the `render` kernel (voxKernel.cu:437-483)
+// =====================================================================================================
+__global__ void __launch_bounds__( TRACE_BLOCK ) kRenderPrimary( SvoDev svo, CameraPinhole cam, int W, int H, int showVertexColor, uchar4* __restrict__ rgba,
+																  float* __restrict__ tOut, int32_t* __restrict__ nMajorOut, uint32_t* __restrict__ vIndexOut,
+																  uint32_t* __restrict__ descentsOut )
+{
+	extern __shared__ uint32_t lds[];
+	const uint32_t lane = threadIdx.x;
+	const uint64_t n = (uint64_t)W * H;
+	for( uint64_t base = (uint64_t)blockIdx.x * TRACE_BLOCK; base < n; base += (uint64_t)gridDim.x * TRACE_BLOCK )
+	{
+		uint64_t pixelIdx = base + lane;
+		if( pixelIdx < n )
+		{
+			int x = (int)( pixelIdx % W );
+			int y = (int)( pixelIdx / W );
+			f3 ro, rd;
+			cameraShoot( cam, &ro, &rd, x, y, 0.5f, 0.5f, W, H );
+			TraceResult r = traceRay<true>( svo, ro, rd, false, lds, TRACE_BLOCK, lane );
+			uchar4 c = make_uchar4( 0, 0, 0, 255 );
+			if( r.t != MVRT_MAXF )
+			{
+				if( showVertexColor )
+				{
+					uint32_t col = svo.attrs[r.vIndex].x;
+					c = make_uchar4( col & 0xFF, ( col >> 8 ) & 0xFF, ( col >> 16 ) & 0xFF, ( col >> 24 ) & 0xFF );
+				}
+				else
+				{
+					f3 hn = getHitN( r.nMajor, rd );
+					f3 color = ( hn + mk3( 1.0f, 1.0f, 1.0f ) ) * 0.5f;
+					c = make_uchar4( (uint8_t)( 255 * color.x + 0.5f ), (uint8_t)( 255 * color.y + 0.5f ), (uint8_t)( 255 * color.z + 0.5f ), 255 );
+				}
+			}
+			if( rgba ) rgba[pixelIdx] = c;
+			if( tOut ) tOut[pixelIdx] = r.t;
+			if( nMajorOut ) nMajorOut[pixelIdx] = r.nMajor;
+			if( vIndexOut ) vIndexOut[pixelIdx] = r.vIndex;
+			if( descentsOut ) descentsOut[pixelIdx] = r.descents;
+		}
+	}
+}
+
+int launchRenderPrimary( const SvoDev& svo, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t, int32_t* nMajor, uint32_t* vIndex,
+						 uint32_t* descents, hipStream_t stream )
+{
+	uint64_t n = (uint64_t)W * H;
+	if( n == 0 ) return 0;
+	size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
+	if( allowLds( kRenderPrimary, lds ) ) return 1;
+	int grid = persistentGrid( n, TRACE_BLOCK, numCUs(), 32 );
+	hipLaunchKernelGGL( kRenderPrimary, dim3( grid ), dim3( TRACE_BLOCK ), lds, stream, svo, cam, W, H, showVertexColor, rgba, t, nMajor, vIndex, descents );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
+// =====================================================================================================
+// Stable compaction: count per 256-item virtual block -> single-workgroup exclusive scan -> rank
+// =====================================================================================================
+#define CBLOCK 256
+
+// number of set flags in each 256-item block
+template <class Pred>
+MVRT_DI void blockCountBody( Pred pred, uint64_t n, uint32_t* __restrict__ blockCount )
+{
+	__shared__ uint32_t waveCnt[CBLOCK / WAVE];
+	const uint64_t nBlocks = ( n + CBLOCK - 1 ) / CBLOCK;
+	for( uint64_t vb = blockIdx.x; vb < nBlocks; vb += gridDim.x )
+	{
+		uint64_t i = vb * CBLOCK + threadIdx.x;
+		bool keep = i < n ? pred( i ) : false;
+		unsigned long long b = __ballot( keep );
+		if( ( threadIdx.x & ( WAVE - 1 ) ) == 0 ) waveCnt[threadIdx.x / WAVE] = __popcll( b );
+		__syncthreads();
+		if( threadIdx.x == 0 ) blockCount[vb] = waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+		__syncthreads();
+	}
+}
+
+// in-block stable rank of a kept item; every thread of the block must call it
+MVRT_DI uint32_t blockRank( bool keep, uint32_t* waveCnt /* LDS, 4 entries */ )
+{
+	unsigned long long b = __ballot( keep );
+	uint32_t lane = threadIdx.x & ( WAVE - 1 );
+	uint32_t w = threadIdx.x / WAVE;
+	uint32_t inWave = __popcll( b & ( ( 1ull << lane ) - 1ull ) );
+	if( lane == 0 ) waveCnt[w] = __popcll( b );
+	__syncthreads();
+	uint32_t off = 0;
+	for( uint32_t k = 0; k < w; k++ ) off += waveCnt[k];
+	__syncthreads();
+	return off + inWave;
+}
+
+// exclusive scan of blockCount[0..nBlocks) in place by ONE workgroup of 1024 threads; total -> *totalOut.
+// nBlocks is read from device memory when nDev != null (n = *nDev items).
+__global__ void __launch_bounds__( 1024 ) kScanBlockCounts( uint32_t* __restrict__ blockCount, uint64_t nItemsHost, const uint32_t* __restrict__ nItemsDev,
+															 uint32_t* __restrict__ totalOut )
+{
+	__shared__ uint32_t part[1024];
+	uint64_t nItems = nItemsDev ? (uint64_t)*nItemsDev : nItemsHost;
+	uint32_t nBlocks = (uint32_t)( ( nItems + CBLOCK - 1 ) / CBLOCK );
+	uint32_t per = ( nBlocks + 1023 ) / 1024;
+	uint32_t beg = threadIdx.x * per;
+	uint32_t end = beg + per < nBlocks ? beg + per : nBlocks;
+	uint32_t sum = 0;
+	for( uint32_t i = beg; i < end; i++ ) sum += blockCount[i];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for( uint32_t off = 1; off < 1024; off <<= 1 ) // Hillis-Steele inclusive over the 1024 partials
+	{
+		uint32_t v = part[threadIdx.x];
+		if( threadIdx.x >= off ) v += part[threadIdx.x - off];
+		__syncthreads();
+		part[threadIdx.x] = v;
+		__syncthreads();
+	}
+	uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+	for( uint32_t i = beg; i < end; i++ )
+	{
+		uint32_t c = blockCount[i];
+		blockCount[i] = run;
+		run += c;
+	}
+	if( threadIdx.x == 1023 && totalOut ) *totalOut = part[1023];
+}
+
+__global__ void __launch_bounds__( CBLOCK ) kCountFlags( const uint8_t* __restrict__ keep, uint64_t n, uint32_t* __restrict__ blockCount )
+{
+	blockCountBody( [=]( uint64_t i ) { return keep[i] != 0; }, n, blockCount );
+}
+__global__ void __launch_bounds__( CBLOCK ) kRankFlags( const uint8_t* __restrict__ keep, uint64_t n, const uint32_t* __restrict__ blockOffset, uint32_t* __restrict__ dstIndex )
+{
+	__shared__ uint32_t waveCnt[CBLOCK / WAVE];
+	const uint64_t nBlocks = ( n + CBLOCK - 1 ) / CBLOCK;
+	for( uint64_t vb = blockIdx.x; vb < nBlocks; vb += gridDim.x )
+	{
+		uint64_t i = vb * CBLOCK + threadIdx.x;
+		bool k = i < n ? keep[i] != 0 : false;
+		uint32_t r = blockRank( k, waveCnt );
+		if( i < n ) dstIndex[i] = k ? blockOffset[vb] + r : 0xFFFFFFFFu;
+	}
+}
+
+int launchCompactIndices( const uint8_t* keep, uint64_t n, uint32_t* dstIndex, uint32_t* kept, uint32_t* blockScratch, hipStream_t stream )
+{
+	int grid = persistentGrid( n, CBLOCK, numCUs(), 8 );
+	hipLaunchKernelGGL( kCountFlags, dim3( grid ), dim3( CBLOCK ), 0, stream, keep, n, blockScratch );
+	hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, blockScratch, n, (const uint32_t*)nullptr, kept );
+	hipLaunchKernelGGL( kRankFlags, dim3( grid ), dim3( CBLOCK ), 0, stream, keep, n, blockScratch, dstIndex );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
+// =====================================================================================================
+// Wavefront path tracer
+// =====================================================================================================
+struct PtParams
+{
+	SvoDev svo;
+	HdriDev hdri;
+	const float2* pmj;
+	CameraPinhole cam;
+	PtFrame frame;
+	PtBuffers buf;
+	int hdriEnabled;  // hdri.isEnabled(), renderCommon.hpp:467-470
+	int extraSamples; // nSampleExtraDirect = hasEmission ? 1 : 0, voxKernel.cu:721
+};
+
+// owned (local) pixel -> global pixel index.  Blocks of 256 pixels dealt round-robin over tiles.
+MVRT_DI uint32_t globalPixel( const PtFrame& f, uint32_t localPixel )
+{
+	uint32_t lb = localPixel / MVRT_TILE_PIXELS;
+	return ( lb * f.tileCount + f.tileIndex ) * MVRT_TILE_PIXELS + ( localPixel % MVRT_TILE_PIXELS );
+}
+
+// number of PMJ dimensions consumed before the shading of depth k (voxKernel.cu:662-666,699-700,724,741)
+MVRT_DI int dimBase( int k, int hdriEnabled, int extraSamples ) { return 2 + k * ( ( hdriEnabled ? 2 : 0 ) + 1 ) + ( k > 0 ? extraSamples : 0 ); }
+
+// ---- generate: camera samples -> primary rays (voxKernel.cu:635-667) -------------------------------
+__global__ void __launch_bounds__( 256 ) kPtGenerate( PtParams P )
+{
+	const uint64_t n = P.frame.validOwnedPixels * MVRT_SPP_PER_STEP;
+	const PathSet& o = P.buf.set[0];
+	for( uint64_t task = (uint64_t)blockIdx.x * 256 + threadIdx.x; task < n; task += (uint64_t)gridDim.x * 256 )
+	{
+		uint32_t localPixel = (uint32_t)( task / MVRT_SPP_PER_STEP );
+		uint32_t localSpp = (uint32_t)( task % MVRT_SPP_PER_STEP );
+		uint32_t pixelIdx = globalPixel( P.frame, localPixel );
+		int x = pixelIdx % P.frame.width;
+		int y = pixelIdx / P.frame.width;
+		uint32_t spp = P.frame.iteration * MVRT_SPP_PER_STEP + localSpp;
+		uint32_t stream = hashCombine2( 0u, pixelIdx );
+		f2 camU = pmjSample2d( P.pmj, spp, 0, stream );
+		f2 lensU = pmjSample2d( P.pmj, spp, 1, stream );
+		f3 ro, rd;
+		cameraShootThinLens( P.cam, &ro, &rd, x, y, camU.x, camU.y, P.frame.width, P.frame.height, lensU.x, lensU.y );
+		o.task[task] = (uint32_t)task;
+		o.rox[task] = ro.x;
+		o.roy[task] = ro.y;
+		o.roz[task] = ro.z;
+		o.rdx[task] = rd.x;
+		o.rdy[task] = rd.y;
+		o.rdz[task] = rd.z;
+	}
+	if( blockIdx.x == 0 && threadIdx.x == 0 )
+	{
+		P.buf.liveCount[0] = (uint32_t)n;
+		atomicAdd( &P.buf.stats[5], (unsigned long long)n );
+	}
+}
+
+// ---- trace: all rays of one stage.  Ray r = kind * n + path; kind 0 bounce/primary, 1 shadow, 2 extra -
+__global__ void __launch_bounds__( TRACE_BLOCK ) kPtTrace( PtParams P, int stage, int setIdx, int nKinds, int shadowKind, int extraKind )
+{
+	extern __shared__ uint32_t lds[];
+	const uint32_t lane = threadIdx.x;
+	const uint64_t n = P.buf.liveCount[stage];
+	const uint64_t total = n * nKinds;
+	const PathSet& in = P.buf.set[setIdx];
+	unsigned long long dNormal = 0, dShadow = 0, nHits = 0;
+	for( uint64_t base = (uint64_t)blockIdx.x * TRACE_BLOCK; base < total; base += (uint64_t)gridDim.x * TRACE_BLOCK )
+	{
+		uint64_t r = base + lane;
+		if( r < total )
+		{
+			int kindSlot = ( r >= n ) + ( r >= 2 * n );
+			uint64_t i = r - (uint64_t)kindSlot * n;
+			int kind = kindSlot == 0 ? 0 : ( kindSlot == 1 ? ( shadowKind ? 1 : 2 ) : 2 );
+			f3 ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
+			f3 rd;
+			if( kind == 0 ) rd = mk3( in.rdx[i], in.rdy[i], in.rdz[i] );
+			else if( kind == 1 ) rd = mk3( P.buf.sx[i], P.buf.sy[i], P.buf.sz[i] );
+			else rd = mk3( P.buf.ex[i], P.buf.ey[i], P.buf.ez[i] );
+			TraceResult h = traceRay<true>( P.svo, ro, rd, kind == 1, lds, TRACE_BLOCK, lane );
+			if( kind == 0 )
+			{
+				P.buf.hitT[i] = h.t;
+				P.buf.hitV[i] = h.vIndex;
+				P.buf.hitN[i] = (uint8_t)h.nMajor;
+			}
+			else if( kind == 1 )
+			{
+				P.buf.hitS[i] = h.t != MVRT_MAXF ? 1 : 0;
+			}
+			else
+			{
+				P.buf.hitE[i] = h.t != MVRT_MAXF ? 1 : 0;
+				P.buf.hitEV[i] = h.vIndex;
+			}
+			if( kind == 1 ) dShadow += h.descents;
+			else
+			{
+				dNormal += h.descents;
+				nHits += h.t != MVRT_MAXF ? 1 : 0;
+			}
+		}
+	}
+	(void)extraKind;
+	dNormal = waveSum( dNormal );
+	dShadow = waveSum( dShadow );
+	nHits = waveSum( nHits );
+	if( lane == 0 )
+	{
+		if( dNormal ) atomicAdd( &P.buf.stats[2], dNormal );
+		if( dShadow ) atomicAdd( &P.buf.stats[3], dShadow );
+		if( nHits ) atomicAdd( &P.buf.stats[4], nHits );
+	}
+}
+
+// ---- count survivors of a stage per 256-path block (a path survives iff its bounce ray hit) ---------
+__global__ void __launch_bounds__( CBLOCK ) kPtCount( PtParams P, int stage )
+{
+	const uint64_t n = P.buf.liveCount[stage];
+	const float* hitT = P.buf.hitT;
+	blockCountBody( [=]( uint64_t i ) { return hitT[i] != MVRT_MAXF; }, n, P.buf.blockCount );
+}
+
+// single thread: ray accounting for the stage that was just traced
+__global__ void kPtAccountRays( PtParams P, int stage, int nKinds, int shadowKind )
+{
+	unsigned long long n = P.buf.liveCount[stage];
+	atomicAdd( &P.buf.stats[0], n * nKinds );
+	if( shadowKind ) atomicAdd( &P.buf.stats[1], n );
+}
+
+// ---- HDRI lookups (renderCommon.hpp:175-180,354-365,367-465) ---------------------------------------
+MVRT_DI f3 hdriSampleNearest( const HdriDev& h, f3 d, bool isPrimary )
+{
+	int w = isPrimary ? h.widthPrimary : h.width;
+	int hh = isPrimary ? h.heightPrimary : h.height;
+	float phi = mvrt_atan2( d.z, d.x ) + MVRT_PI;
+	float theta = mvrt_atan2( sqrtf( d.x * d.x + d.z * d.z ), d.y );
+	float u = phi / ( MVRT_PI * 2.0f );
+	float v = theta / MVRT_PI;
+	int x = (int)smin( smax( u * w, 0.0f ), (float)( w - 1.0f ) );
+	int y = (int)smin( smax( v * hh, 0.0f ), (float)( hh - 1.0f ) );
+	uint64_t index = (uint64_t)y * w + x;
+	float4 c = ( isPrimary && h.pixelsPrimary ) ? h.pixelsPrimary[index] : h.pixels[index];
+	return mk3( c.x, c.y, c.z ) * h.scale;
+}
+MVRT_DI uint32_t satH( const HdriDev& h, const uint32_t* s, uint32_t x ) { return x == 0 ? 0u : s[h.width * ( h.height - 1 ) + x - 1]; }
+MVRT_DI uint32_t satV( const HdriDev& h, const uint32_t* s, uint32_t x, uint32_t y )
+{
+	if( y == 0 ) return 0u;
+	uint32_t s0 = x == 0 ? 0u : s[h.width * ( y - 1 ) + ( x - 1 )];
+	uint32_t s1 = s[h.width * ( y - 1 ) + x];
+	return s1 - s0;
+}
+MVRT_DI uint32_t satCount( const HdriDev& h, const uint32_t* s, uint32_t x, uint32_t y )
+{
+	uint32_t a = ( x == 0 || y == 0 ) ? 0u : s[h.width * ( y - 1 ) + ( x - 1 )];
+	uint32_t b = ( y == 0 ) ? 0u : s[h.width * ( y - 1 ) + x];
+	uint32_t c = ( x == 0 ) ? 0u : s[h.width * y + ( x - 1 )];
+	uint32_t d = s[h.width * y + x];
+	return ( d - b ) + ( a - c );
+}
+MVRT_DI void hdriImportanceSample( const HdriDev& h, f3* dir, f3* L, float* pdf, f3 N, float u0, float u1, float u2, float u3 )
+{
+	const uint32_t* s = h.sat;
+	const float k = 0.8f;
+	if( k < N.x ) s = h.sats[0];
+	else if( N.x < -k ) s = h.sats[1];
+	else if( k < N.y ) s = h.sats[2];
+	else if( N.y < -k ) s = h.sats[3];
+	else if( k < N.z ) s = h.sats[4];
+	else if( N.z < -k ) s = h.sats[5];
+
+	int i = 0, j = h.width; // upper_bound_f, renderCommon.hpp:182-202
+	while( i < j )
+	{
+		int m = ( i + j ) / 2;
+		float value = (float)satH( h, s, m ) / 4294967296.0f; // (float)0xFFFFFFFFu
+		if( value <= u0 ) i = m + 1;
+		else j = m;
+	}
+	uint32_t X = (uint32_t)( i - 1 );
+	uint32_t vol = satH( h, s, X + 1 ) - satH( h, s, X );
+	i = 0;
+	j = h.height;
+	while( i < j )
+	{
+		int m = ( i + j ) / 2;
+		float value = (float)satV( h, s, X, m ) / (float)vol;
+		if( value <= u1 ) i = m + 1;
+		else j = m;
+	}
+	uint32_t Y = (uint32_t)( i - 1 );
+	float pSelection = (float)satCount( h, s, X, Y ) / 4294967296.0f;
+	float dTheta = MVRT_PI / (float)h.height;
+	float dPhi = 2.0f * MVRT_PI / (float)h.width;
+	float theta = Y * dTheta;
+	float dH = 2.0f * mvrt_sin( dTheta * 0.5f ) * mvrt_sin( dTheta * 0.5f + theta );
+	float sr = dH * dPhi;
+	float sY = mixf( mvrt_cos( theta ), mvrt_cos( theta + dTheta ), u2 );
+	float phi = dPhi * ( (float)X + u3 ) + MVRT_PI;
+	float sX, sZ;
+	mvrt_sincos( phi, &sZ, &sX );
+	float sinTheta = sqrtf( smax( 1.0f - sY * sY, 0.0f ) );
+	*dir = mk3( sX * sinTheta, sY, sZ * sinTheta );
+	*pdf = pSelection / sr;
+	float4 color = h.pixels[Y * h.width + X];
+	*L = mk3( color.x, color.y, color.z ) * h.scale;
+}
+
+// sampleLambertian + GetOrthonormalBasis, renderCommon.hpp:119-151
+MVRT_DI f3 sampleLambertian( float a, float b, f3 Ng )
+{
+	float r = sqrtf( a );
+	float theta = b * MVRT_PI * 2.0f;
+	float sn, cs;
+	mvrt_sincos( theta, &sn, &cs );
+	float x = r * cs;
+	float y = r * sn;
+	float z = sqrtf( smax( 1.0f - a, 0.0f ) );
+	const float sign = copysignf( 1.0f, Ng.z );
+	const float aa = -1.0f / ( sign + Ng.z );
+	const float bb = Ng.x * Ng.y * aa;
+	f3 xaxis = mk3( 1.0f + sign * Ng.x * Ng.x * aa, sign * bb, -sign * Ng.x );
+	f3 yaxis = mk3( bb, sign + Ng.y * Ng.y * aa, -Ng.y );
+	return xaxis * x + yaxis * y + Ng * z;
+}
+
+MVRT_DI f3 voxelEmission( const SvoDev& s, uint32_t vIndex, bool withScale ) // IntersectorOctreeGPU.hpp:256-259
+{
+	return rawReflectance( s.attrs[vIndex].y ) * ( withScale ? s.emissionScale : 1.0f );
+}
+
+// ---- shade + compact: stage k consumes the hits of trace k, adds the contributions that became known,
+// and for paths whose bounce ray hit, shades the hit (depth k of the reference loop, voxKernel.cu:691-760),
+// writing the survivor to its STABLE compacted slot of the other PathSet. --------------------------------
+__global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int inSet )
+{
+	__shared__ uint32_t waveCnt[CBLOCK / WAVE];
+	const uint64_t n = P.buf.liveCount[stage];
+	const PathSet& in = P.buf.set[inSet];
+	const PathSet& out = P.buf.set[inSet ^ 1];
+	const bool lastStage = stage >= MVRT_MAX_DEPTH;
+	const uint64_t nBlocks = ( n + CBLOCK - 1 ) / CBLOCK;
+	for( uint64_t vb = blockIdx.x; vb < nBlocks; vb += gridDim.x )
+	{
+		const uint64_t i = vb * CBLOCK + threadIdx.x;
+		const bool valid = i < n;
+		bool alive = false;
+		uint32_t task = 0, vIndex = 0;
+		int nMajor = 0;
+		float t = MVRT_MAXF;
+		f3 ro, rd, T, L;
+		if( valid )
+		{
+			task = in.task[i];
+			ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
+			rd = mk3( in.rdx[i], in.rdy[i], in.rdz[i] );
+			t = P.buf.hitT[i];
+			vIndex = P.buf.hitV[i];
+			nMajor = P.buf.hitN[i];
+			const bool hit = t != MVRT_MAXF;
+			if( stage == 0 )
+			{
+				T = mk3( 1.0f, 1.0f, 1.0f );
+				L = mk3( 0.0f, 0.0f, 0.0f );
+				if( !hit ) // voxKernel.cu:678-684
+				{
+					L = L + T * hdriSampleNearest( P.hdri, rd, true );
+				}
+				else // :685-689
+				{
+					L = L + T * voxelEmission( P.svo, vIndex, false );
+				}
+			}
+			else
+			{
+				T = mk3( in.Tx[i], in.Ty[i], in.Tz[i] );
+				L = mk3( in.Lx[i], in.Ly[i], in.Lz[i] );
+				if( P.hdriEnabled && P.buf.hitS[i] == 0 ) // :712-715, contribution computed when the ray was generated
+				{
+					L = L + mk3( in.nx[i], in.ny[i], in.nz[i] );
+				}
+				if( stage == 1 && P.extraSamples ) // :722-738
+				{
+					if( P.buf.hitE[i] )
+					{
+						f3 Le = voxelEmission( P.svo, P.buf.hitEV[i], true );
+						L = L + T * Le / (float)( 1 + P.extraSamples );
+					}
+				}
+				if( hit ) // :750-759
+				{
+					f3 Le = voxelEmission( P.svo, vIndex, true );
+					L = L + T * Le * ( stage == 1 ? 1.0f / (float)( 1 + P.extraSamples ) : 1.0f );
+				}
+			}
+			alive = hit && !lastStage;
+			if( !alive )
+			{
+				P.buf.Lsx[task] = L.x;
+				P.buf.Lsy[task] = L.y;
+				P.buf.Lsz[task] = L.z;
+			}
+		}
+		if( lastStage ) continue; // nothing survives stage 8; uniform across the grid
+		const uint32_t rank = blockRank( alive, waveCnt );
+		if( alive )
+		{
+			const uint64_t j = (uint64_t)P.buf.blockCount[vb] + rank;
+			// depth = stage of the reference loop
+			const uint32_t localPixel = task / MVRT_SPP_PER_STEP;
+			const uint32_t spp = P.frame.iteration * MVRT_SPP_PER_STEP + ( task % MVRT_SPP_PER_STEP );
+			const uint32_t stream = hashCombine2( 0u, globalPixel( P.frame, localPixel ) );
+			int dim = dimBase( stage, P.hdriEnabled, P.extraSamples );
+			const f3 R = rawReflectance( P.svo.attrs[vIndex].x ); // :693
+			const f3 hitN = getHitN( nMajor, rd );				  // :694
+			const f3 hitP = ro + rd * t;						  // :695
+			f3 nee = mk3( 0.0f, 0.0f, 0.0f );
+			if( P.hdriEnabled ) // :697-716
+			{
+				f2 u01 = pmjSample2d( P.pmj, spp, dim++, stream );
+				f2 u23 = pmjSample2d( P.pmj, spp, dim++, stream );
+				f3 sdir, emissive;
+				float p;
+				hdriImportanceSample( P.hdri, &sdir, &emissive, &p, hitN, u01.x, u01.y, u23.x, u23.y );
+				nee = T * ( R / MVRT_PI ) * smax( dot3( hitN, sdir ), 0.0f ) * emissive / p;
+				P.buf.sx[j] = sdir.x;
+				P.buf.sy[j] = sdir.y;
+				P.buf.sz[j] = sdir.z;
+			}
+			T = T * R;								// :718
+			if( stage == 0 && P.extraSamples ) // :721-726
+			{
+				f2 u = pmjSample2d( P.pmj, spp, dim++, stream );
+				f3 edir = sampleLambertian( u.x, u.y, hitN );
+				P.buf.ex[j] = edir.x;
+				P.buf.ey[j] = edir.y;
+				P.buf.ez[j] = edir.z;
+			}
+			f2 u = pmjSample2d( P.pmj, spp, dim++, stream ); // :741-745
+			f3 bdir = sampleLambertian( u.x, u.y, hitN );
+			out.task[j] = task;
+			out.rox[j] = hitP.x;
+			out.roy[j] = hitP.y;
+			out.roz[j] = hitP.z;
+			out.rdx[j] = bdir.x;
+			out.rdy[j] = bdir.y;
+			out.rdz[j] = bdir.z;
+			out.Tx[j] = T.x;
+			out.Ty[j] = T.y;
+			out.Tz[j] = T.z;
+			out.Lx[j] = L.x;
+			out.Ly[j] = L.y;
+			out.Lz[j] = L.z;
+			out.nx[j] = nee.x;
+			out.ny[j] = nee.y;
+			out.nz[j] = nee.z;
+		}
+	}
+}
+
+// ---- accumulate: frameBuffer[p].xyz += sum of the 16 samples in ascending spp order, .w += 16 -------
+// (voxKernel.cu:763-774; the reference's LDS atomicAdd order is nondeterministic, ascending is ours)
+__global__ void __launch_bounds__( 256 ) kPtAccumulate( PtParams P, float4* __restrict__ fb )
+{
+	const uint64_t n = P.frame.validOwnedPixels;
+	for( uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256 )
+	{
+		const float4* sx = (const float4*)( P.buf.Lsx + p * MVRT_SPP_PER_STEP );
+		const float4* sy = (const float4*)( P.buf.Lsy + p * MVRT_SPP_PER_STEP );
+		const float4* sz = (const float4*)( P.buf.Lsz + p * MVRT_SPP_PER_STEP );
+		float ax = 0.0f, ay = 0.0f, az = 0.0f;
+#pragma unroll
+		for( int q = 0; q < MVRT_SPP_PER_STEP / 4; q++ )
+		{
+			float4 vx = sx[q], vy = sy[q], vz = sz[q];
+			ax += vx.x; ax += vx.y; ax += vx.z; ax += vx.w;
+			ay += vy.x; ay += vy.y; ay += vy.z; ay += vy.w;
+			az += vz.x; az += vz.y; az += vz.z; az += vz.w;
+		}
+		float4 v = fb[p];
+		v.x += ax;
+		v.y += ay;
+		v.z += az;
+		v.w += (float)MVRT_SPP_PER_STEP;
+		fb[p] = v;
+	}
+}
+
+int launchPtStep( const SvoDev& svo, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
+				  int nCUs, PtProfiler* prof, hipStream_t stream )
+{
+	PtParams P;
+	P.svo = svo;
+	P.hdri = hdri;
+	P.pmj = pmj;
+	P.cam = cam;
+	P.frame = frame;
+	P.buf = buf;
+	P.hdriEnabled = ( 0.0f < hdri.scale ) ? 1 : 0;
+	P.extraSamples = svo.hasEmission ? 1 : 0;
+	if( nCUs <= 0 ) nCUs = numCUs();
+
+	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP;
+	if( nSamples == 0 ) return 0;
+	if( nSamples > buf.cap )
+	{
+		mvrtSetError( "path buffers too small: %llu samples > capacity %llu", (unsigned long long)nSamples, (unsigned long long)buf.cap );
+		return 1;
+	}
+	const size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
+	if( allowLds( kPtTrace, lds ) ) return 1;
+
+#define PROF_BEGIN( c ) if( prof ) prof->begin( c, stream )
+#define PROF_END() if( prof ) prof->end( stream )
+
+	PROF_BEGIN( MVRT_K_OTHER );
+	hipLaunchKernelGGL( kPtGenerate, dim3( persistentGrid( nSamples, 256, nCUs, 8 ) ), dim3( 256 ), 0, stream, P );
+	PROF_END();
+
+	for( int stage = 0; stage <= MVRT_MAX_DEPTH; stage++ )
+	{
+		const int setIdx = stage & 1;
+		const int shadowKind = ( stage > 0 && P.hdriEnabled ) ? 1 : 0;
+		const int extraKind = ( stage == 1 && P.extraSamples ) ? 1 : 0;
+		const int nKinds = 1 + shadowKind + extraKind;
+		// upper bound for the grid: every stage has at most nSamples live paths
+		const int traceGrid = persistentGrid( nSamples * nKinds, TRACE_BLOCK, nCUs, 32 );
+		PROF_BEGIN( MVRT_K_TRACE );
+		hipLaunchKernelGGL( kPtTrace, dim3( traceGrid ), dim3( TRACE_BLOCK ), lds, stream, P, stage, setIdx, nKinds, shadowKind, extraKind );
+		PROF_END();
+		PROF_BEGIN( MVRT_K_OTHER );
+		hipLaunchKernelGGL( kPtAccountRays, dim3( 1 ), dim3( 1 ), 0, stream, P, stage, nKinds, shadowKind );
+		if( stage < MVRT_MAX_DEPTH )
+		{
+			hipLaunchKernelGGL( kPtCount, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage );
+			hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, buf.blockCount, (uint64_t)0, (const uint32_t*)( buf.liveCount + stage ),
+								buf.liveCount + stage + 1 );
+		}
+		PROF_END();
+		PROF_BEGIN( MVRT_K_SHADE );
+		hipLaunchKernelGGL( kPtShade, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
+		PROF_END();
+	}
+	PROF_BEGIN( MVRT_K_OTHER );
+	hipLaunchKernelGGL( kPtAccumulate, dim3( persistentGrid( frame.validOwnedPixels, 256, nCUs, 8 ) ), dim3( 256 ), 0, stream, P, frameBuffer );
+	PROF_END();
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}

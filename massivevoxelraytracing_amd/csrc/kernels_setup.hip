@@ -1,0 +1,164 @@
+// kernels_setup.hip -- kernels around the hot path: node layout conversion, HDRI summed-area tables
+// (voxKernel.cu:485-608 semantics), resolve (voxKernel.cu:779-795), multi-GPU tile assembly.
+#include "launch.h"
+
+// ---- reference 68-byte AoS nodes <-> one 64-byte line per node -----------------------------------------
+__global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restrict__ nodes68, uint32_t nNodes, Node64* __restrict__ out, uint8_t* __restrict__ masks )
+{
+	// one thread per (node, dword): 16 payload dwords per node
+	uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t node = gid / 16;
+	uint32_t w = gid % 16;
+	if( node >= nNodes ) return;
+	const uint32_t* src = (const uint32_t*)( nodes68 + node * 68 ); // 68 is a multiple of 4: aligned dwords
+	( (uint32_t*)( out + node ) )[w] = src[1 + w];
+	if( w == 0 ) masks[node] = (uint8_t)( src[0] & 0xFF );
+}
+int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, hipStream_t stream )
+{
+	if( nNodes == 0 ) return 0;
+	hipLaunchKernelGGL( kConvertNodes, dim3( divUp( (uint64_t)nNodes * 16, 256 ) ), dim3( 256 ), 0, stream, nodes68, nNodes, out, masks );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+__global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint32_t nNodes, uint8_t* __restrict__ nodes68 )
+{
+	uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t node = gid / 17;
+	uint32_t w = gid % 17;
+	if( node >= nNodes ) return;
+	uint32_t* dst = (uint32_t*)( nodes68 + node * 68 );
+	dst[w] = w == 0 ? (uint32_t)masks[node] : ( (const uint32_t*)( nodes + node ) )[w - 1];
+}
+int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, hipStream_t stream )
+{
+	if( nNodes == 0 ) return 0;
+	hipLaunchKernelGGL( kNodesTo68, dim3( divUp( (uint64_t)nNodes * 17, 256 ) ), dim3( 256 ), 0, stream, nodes, masks, nNodes, nodes68 );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
+// ---- HDRI importance tables ------------------------------------------------------------------------------
+// HDRIstoreImportance, voxKernel.cu:485-524
+__global__ void kHdriImportance( const float4* __restrict__ pixels, int w, int h, double* __restrict__ sat, int cosWeighted, f3 axis )
+{
+	uint32_t pixelX = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t pixelY = blockIdx.y * blockDim.y + threadIdx.y;
+	if( (uint32_t)w <= pixelX || (uint32_t)h <= pixelY ) return;
+	uint32_t pixelIdx = pixelY * w + pixelX;
+	float dTheta = MVRT_PI / (float)h;
+	float dPhi = 2.0f * MVRT_PI / (float)w;
+	float theta = pixelY * dTheta;
+	float dH = 2.0f * mvrt_sin( dTheta * 0.5f ) * mvrt_sin( dTheta * 0.5f + theta );
+	float sr = dH * dPhi;
+	float4 color = pixels[pixelIdx];
+	float wgt = 1.0f;
+	if( cosWeighted )
+	{
+		float sY = mixf( mvrt_cos( theta ), mvrt_cos( theta + dTheta ), 0.5f );
+		float phi = dPhi * ( (float)pixelX + 0.5f ) + MVRT_PI;
+		float sX = mvrt_cos( phi );
+		float sZ = mvrt_sin( phi );
+		float sinTheta = sqrtf( smax( 1.0f - sY * sY, 0.0f ) );
+		f3 dirCenter = mk3( sX * sinTheta, sY, sZ * sinTheta );
+		wgt = smax( dot3( axis, dirCenter ), 0.0f );
+	}
+	float lum = 0.2126f * color.x + 0.7152f * color.y + 0.0722f * color.z; // luminance, renderCommon.hpp:168-172
+	sat[pixelIdx] = lum * sr * wgt;
+}
+
+// Inclusive prefix sums of rows (horizontal != 0) or columns in f64.  The ADDITION ORDER is part of the
+// result (f64 rounding feeds the u32 tables), so it is fixed to the reference's: 512-wide chunks, each
+// scanned Hillis-Steele in LDS, carried by a running prefix (voxKernel.cu:526-598).
+#define SAT_BLOCK 512
+__global__ void __launch_bounds__( SAT_BLOCK ) kSatScan( int w, int h, double* __restrict__ sat, int horizontal )
+{
+	__shared__ double s[SAT_BLOCK];
+	const int line = blockIdx.x;
+	const int len = horizontal ? w : h;
+	double prefix = 0.0;
+	for( int i = 0; i < len; i += SAT_BLOCK )
+	{
+		const int k = i + threadIdx.x;
+		const uint64_t idx = horizontal ? (uint64_t)line * w + k : (uint64_t)k * w + line;
+		s[threadIdx.x] = k < len ? sat[idx] : 0.0;
+		__syncthreads();
+		for( uint32_t off = 1; off < SAT_BLOCK; off <<= 1 )
+		{
+			double x = s[threadIdx.x];
+			if( off <= threadIdx.x ) x += s[threadIdx.x - off];
+			__syncthreads();
+			s[threadIdx.x] = x;
+			__syncthreads();
+		}
+		double sum = s[SAT_BLOCK - 1];
+		__syncthreads();
+		s[threadIdx.x] += prefix;
+		__syncthreads();
+		prefix += sum;
+		if( k < len ) sat[idx] = s[threadIdx.x];
+		__syncthreads();
+	}
+}
+// buildSAT2u32, voxKernel.cu:600-608
+__global__ void kSatToU32( uint32_t* __restrict__ satU32, const double* __restrict__ satF64, int n )
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	double sum = satF64[n - 1];
+	if( i < n ) satU32[i] = (uint32_t)( satF64[i] / ( sum ) * (double)0xFFFFFFFFu );
+}
+int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream )
+{
+	hipLaunchKernelGGL( kHdriImportance, dim3( divUp( w, 8 ), divUp( h, 8 ) ), dim3( 8, 8 ), 0, stream, pixels, w, h, satF64, cosWeighted, axis );
+	hipLaunchKernelGGL( kSatScan, dim3( h ), dim3( SAT_BLOCK ), 0, stream, w, h, satF64, 1 );
+	hipLaunchKernelGGL( kSatScan, dim3( w ), dim3( SAT_BLOCK ), 0, stream, w, h, satF64, 0 );
+	hipLaunchKernelGGL( kSatToU32, dim3( divUp( (uint64_t)w * h, 64 ) ), dim3( 64 ), 0, stream, satOut, satF64, w * h );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
+// ---- renderResolve, voxKernel.cu:779-795 ------------------------------------------------------------------
+__global__ void __launch_bounds__( 256 ) kResolve( const float4* __restrict__ fb, uint64_t n, uchar4* __restrict__ out )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256 )
+	{
+		float4 v = fb[i];
+		int r = (int)( 255 * mvrt_pow( v.x / v.w, 1.0f / 2.2f ) + 0.5f );
+		int g = (int)( 255 * mvrt_pow( v.y / v.w, 1.0f / 2.2f ) + 0.5f );
+		int b = (int)( 255 * mvrt_pow( v.z / v.w, 1.0f / 2.2f ) + 0.5f );
+		out[i] = make_uchar4( (uint8_t)( r < 255 ? r : 255 ), (uint8_t)( g < 255 ? g : 255 ), (uint8_t)( b < 255 ? b : 255 ), 255 );
+	}
+}
+int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream )
+{
+	if( n == 0 ) return 0;
+	uint32_t grid = divUp( n, 256 );
+	if( grid > 2048 ) grid = 2048;
+	hipLaunchKernelGGL( kResolve, dim3( grid ), dim3( 256 ), 0, stream, fb, n, out );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
+// ---- tile assembly after the RCCL all-gather --------------------------------------------------------------
+// gathered: tileCount buffers of rankStridePixels float4, each holding that rank's owned pixels in block
+// order (block b of the frame -> rank b % tileCount, local block b / tileCount).
+__global__ void __launch_bounds__( 256 ) kAssembleTiles( const float4* __restrict__ gathered, int tileCount, uint64_t rankStride, uint64_t nPixels, float4* __restrict__ frame )
+{
+	for( uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < nPixels; p += (uint64_t)gridDim.x * 256 )
+	{
+		uint64_t b = p / MVRT_TILE_PIXELS;
+		uint64_t rank = b % tileCount;
+		uint64_t local = ( b / tileCount ) * MVRT_TILE_PIXELS + ( p % MVRT_TILE_PIXELS );
+		frame[p] = gathered[rank * rankStride + local];
+	}
+}
+int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStridePixels, int W, int H, float4* frame, hipStream_t stream )
+{
+	uint64_t n = (uint64_t)W * H;
+	if( n == 0 ) return 0;
+	uint32_t grid = divUp( n, 256 );
+	if( grid > 2048 ) grid = 2048;
+	hipLaunchKernelGGL( kAssembleTiles, dim3( grid ), dim3( 256 ), 0, stream, gathered, tileCount, rankStridePixels, n, frame );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}

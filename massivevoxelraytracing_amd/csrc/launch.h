@@ -1,0 +1,82 @@
+// launch.h -- host-side launch wrappers implemented in the .hip translation units.
+#pragma once
+#include "mvrt_common.h"
+
+// ---- wavefront path-tracer work buffers (all device pointers, capacity `cap` paths) ---------------
+struct PathSet // ping-ponged between shade stages (compacted by the writer)
+{
+	uint32_t* task;		   // local sample id = ownedPixel * 16 + localSpp
+	float *rox, *roy, *roz; // ray origin (stage k>0: the hit point the bounce leaves from)
+	float *rdx, *rdy, *rdz; // ray direction (stage k>0: the Lambert bounce direction)
+	float *Tx, *Ty, *Tz;	// throughput after the last T *= R
+	float *Lx, *Ly, *Lz;	// radiance accumulated so far
+	float *nx, *ny, *nz;	// pending next-event contribution, added if the shadow ray misses
+};
+struct PtBuffers
+{
+	PathSet set[2];
+	float *sx, *sy, *sz; // shadow-ray direction (kind 1), origin = ro
+	float *ex, *ey, *ez; // extra Lambert ray direction (kind 2, stage 1 only), origin = ro
+	// hit records written by the traversal kernel, one array per ray kind
+	float* hitT;	  // kind 0: t (MAX_FLOAT = miss)
+	uint32_t* hitV;	  // kind 0: vIndex
+	uint8_t* hitN;	  // kind 0: nMajor
+	uint8_t* hitS;	  // kind 1: 1 if the shadow ray is occluded
+	uint8_t* hitE;	  // kind 2: 1 if the extra ray hit
+	uint32_t* hitEV;  // kind 2: vIndex
+	float *Lsx, *Lsy, *Lsz; // final radiance per sample, indexed by task (read by accumulate)
+	uint32_t* blockCount; // survivors per 256-path virtual block; exclusive-scanned in place
+	uint32_t* liveCount;  // [stage] number of live paths entering stage k (0..9)
+	unsigned long long* stats; // [0] rays [1] shadowRays [2] descents [3] shadowDescents [4] hits [5] samples
+	uint64_t cap;
+};
+
+struct PtFrame
+{
+	int width, height;
+	int tileIndex, tileCount;
+	uint64_t ownedPixels;	   // padded to whole 256-pixel blocks
+	uint64_t validOwnedPixels; // pixels that exist in the image
+	int iteration;
+};
+
+enum MvrtKernelClass
+{
+	MVRT_K_TRACE = 0,
+	MVRT_K_SHADE = 1,
+	MVRT_K_OTHER = 2
+};
+
+int launchTraceBatch( const SvoDev& svo, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy, const float* rdz,
+					  const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream );
+int launchRenderPrimary( const SvoDev& svo, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t, int32_t* nMajor, uint32_t* vIndex,
+						 uint32_t* descents, hipStream_t stream );
+int launchCompactIndices( const uint8_t* keep, uint64_t n, uint32_t* dstIndex, uint32_t* kept, uint32_t* blockScratch, hipStream_t stream );
+
+// one PathTracer::step().  `mark(class)` is called before/after each kernel when profiling is on.
+struct PtProfiler
+{
+	virtual void begin( int kernelClass, hipStream_t s ) = 0;
+	virtual void end( hipStream_t s ) = 0;
+};
+int launchPtStep( const SvoDev& svo, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
+				  int numCUs, PtProfiler* prof, hipStream_t stream );
+
+int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream );
+int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStridePixels, int W, int H, float4* frame, hipStream_t stream );
+int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, hipStream_t stream );
+int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, hipStream_t stream );
+int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
+
+// GPU SVO construction (svo_build.hip)
+struct SvoBuildResult
+{
+	Node64* nodes;
+	uint8_t* masks;
+	uint2* attrs;
+	uint64_t* morton; // kept for parity checks (sorted unique codes)
+	uint32_t nNodes, nVoxels, hasEmission;
+	uint64_t totalDumped;
+};
+int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const float* emisHost, uint64_t nVertices, f3 origin, float dps, int gridRes, hipStream_t stream,
+						   SvoBuildResult* out );

@@ -1,0 +1,288 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C-ABI,
+against the CPU oracle on the same inputs.  Bars: bit-exact for (t, nMajor, vIndex), descents,
+compaction indices, per-sample radiance, frame buffers and resolved bytes (the oracle runs in
+mathMode 1 = the shared deterministic transcendental set, see include/mvrt_detmath.h)."""
+import numpy as np
+import pytest
+
+from common import bunny_tris, golden, hdr_bytes, position_colors, probe_camera
+
+pytestmark = pytest.mark.gpu
+
+G = golden()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def mv():
+    import massivevoxelraytracing_amd as m
+    m.lib()
+    assert m.device_count() >= 1
+    print("device:", m.device_name())
+    return m
+
+
+@pytest.fixture(scope="module")
+def bunny256(O):
+    return O.build_scene_from_triangles(bunny_tris(), 256)
+
+
+@pytest.fixture(scope="module")
+def bunny256_color(O):
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    sc = O.build_scene_from_triangles(tris, 256, cols, emis)
+    assert sc.has_emission == 1
+    return sc
+
+
+def upload(mv, sc, embedded=True):
+    svo = mv.IntersectorOctreeGPU()
+    svo.upload(sc.nodes, sc.attrs, sc.origin, sc.dps, sc.grid_res, sc.has_emission, embeddedMask=embedded)
+    return svo
+
+
+def random_rays(sc, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = sc.bounds()
+    c = (lo + hi) / 2
+    ext = (hi - lo).max()
+    ro = (c + (rng.random((n, 3)) - 0.5) * ext * 2.5).astype(np.float32)
+    tgt = (lo + rng.random((n, 3)) * (hi - lo)).astype(np.float32)
+    rd = (tgt - ro).astype(np.float32)
+    # a share of axis-parallel and zero-component directions (the 1/0 clamp path, voxCommon.hpp:265-269)
+    k = n // 10
+    rd[:k, 0] = 0.0
+    rd[k:2 * k, 1] = 0.0
+    rd[2 * k:3 * k, 2] = 0.0
+    rd[3 * k:3 * k + 50] = np.array([0, 0, -1], np.float32)
+    # rays starting inside the volume
+    ro[4 * k:5 * k] = (lo + rng.random((k, 3)) * (hi - lo)).astype(np.float32)
+    return ro, rd
+
+
+def assert_hits_equal(a, b):
+    assert np.array_equal(a["t"], b["t"])
+    hit = a["t"] != np.float32(3.402823466e38)
+    assert np.array_equal(a["nMajor"][hit], b["nMajor"][hit])
+    assert np.array_equal(a["vIndex"][hit], b["vIndex"][hit])
+    assert (b["nMajor"][~hit] == -1).all()
+    if "descents" in a and "descents" in b:
+        assert np.array_equal(a["descents"], b["descents"])
+
+
+def test_trace_batch_bit_exact(mv, O, bunny256):
+    svo = upload(mv, bunny256)
+    ro, rd = random_rays(bunny256, 200_000, 7)
+    sh = (np.arange(len(ro)) % 3 == 0).astype(np.uint8)
+    want = bunny256.trace(ro, rd, sh, threads=8, want_descents=True)
+    got = svo.intersect(ro, rd, sh, want_descents=True)
+    assert_hits_equal(want, got)
+    assert (got["vIndex"][sh == 1] == 0).all()  # shadow rays never accumulate vIndex
+    assert (want["t"] != O.MAX_FLOAT).sum() > 10000
+
+
+def test_trace_empty_and_ragged_batches(mv, O, bunny256):
+    svo = upload(mv, bunny256)
+    assert len(svo.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))["t"]) == 0
+    for n in (1, 63, 64, 65, 257):
+        ro, rd = random_rays(bunny256, n + 400, n)
+        ro, rd = ro[:n], rd[:n]
+        assert_hits_equal(bunny256.trace(ro, rd, want_descents=True), svo.intersect(ro, rd, want_descents=True))
+
+
+def test_trace_non_embedded_variant(mv, O, bunny256):
+    """mask fetched from the node (voxCommon.hpp:353-356) on a non-DAG tree: same hits as the DAG"""
+    nodes = O.build_octree(bunny256.morton, 256, dag=False, embed=False)
+    plain = O.Scene(nodes, bunny256.attrs, bunny256.origin, bunny256.dps, 256, embedded=False)
+    svo = upload(mv, plain, embedded=False)
+    ro, rd = random_rays(bunny256, 50_000, 11)
+    want = bunny256.trace(ro, rd, want_descents=True)
+    assert_hits_equal(plain.trace(ro, rd, want_descents=True), want)
+    assert_hits_equal(want, svo.intersect(ro, rd, want_descents=True))
+
+
+def test_render_primary_golden_and_oracle(mv, O, bunny256):
+    svo = upload(mv, bunny256)
+    cam = probe_camera(bunny256.origin, bunny256.dps, 256)
+    got = svo.render(cam, 1920, 1080)
+    g = G["bunny"]["256"]["primary_1080p"]
+    hit = got["t"] != O.MAX_FLOAT
+    nm = got["nMajor"][hit]
+    assert int(hit.sum()) == g["hits"]
+    assert [int((nm == k).sum()) for k in (0, 1, 2)] == g["nMajor_z_x_y"]
+    assert int(got["vIndex"][hit].astype(np.uint64).sum()) == g["sum_vIndex"]
+    want = bunny256.render_primary(cam, 1920, 1080, threads=8)
+    assert_hits_equal(want, got)
+    assert np.array_equal(want["rgba"], got["rgba"])
+    small = svo.render(cam, 256, 144, want_hits=False)
+    assert int(small["rgba"].astype(np.uint64).sum()) == G["render_normals_256x144_bytesum"]
+
+
+def test_render_vertex_colors(mv, O, bunny256_color):
+    svo = upload(mv, bunny256_color)
+    cam = probe_camera(bunny256_color.origin, bunny256_color.dps, 256)
+    got = svo.render(cam, 333, 177, showVertexColor=True)  # not a multiple of 64
+    want = bunny256_color.render_primary(cam, 333, 177, show_vertex_color=True, threads=8)
+    assert np.array_equal(want["rgba"], got["rgba"])
+    assert_hits_equal(want, got)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 257, 1000, 65536, 1_000_003])
+def test_compaction_indices_bit_exact(mv, O, n):
+    rng = np.random.default_rng(n)
+    for density in (0.0, 0.13, 0.9, 1.0):
+        keep = (rng.random(n) < density).astype(np.uint8)
+        dst_want, src_want = O.compact_indices(keep)
+        dst, kept = mv.compact_indices(keep)
+        assert kept == len(src_want)
+        assert np.array_equal(dst, dst_want)
+
+
+def make_pt(mv, O, sc, w, h, rgba, hw, hh, tile=(0, 1), hdri_scale=None):
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.set_tile(*tile)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    pt.loadHDRIPixels(None, rgba, hw, hh, rgba, hw, hh)
+    if hdri_scale is not None:
+        pt.set_hdri_scale(hdri_scale)
+    pt.m_intersectorOctreeGPU.upload(sc.nodes, sc.attrs, sc.origin, sc.dps, sc.grid_res, sc.has_emission)
+    return pt
+
+
+@pytest.fixture(scope="module")
+def hdr(O):
+    return O.decode_rgbe(hdr_bytes())
+
+
+def test_hdri_tables_bit_exact(mv, O, bunny256, hdr):
+    rgba, w, h = hdr
+    pt = make_pt(mv, O, bunny256, 64, 64, rgba, w, h)
+    H = O.HDRI(rgba, w, h, rgba, w, h, math_mode=1)
+    for which in range(7):
+        assert np.array_equal(pt.hdri_sat(which, w, h), H.sat(which)), which
+
+
+@pytest.mark.parametrize("w,h,iters", [(128, 72, 2), (100, 37, 1)])
+def test_path_tracer_bit_exact(mv, O, bunny256_color, hdr, w, h, iters):
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
+    pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb = np.zeros((w * h, 4), np.float32)
+    tot = dict(rays=0, shadowRays=0, descents=0, shadowDescents=0, hits=0, samples=0)
+    for it in range(iters):
+        pt.step(None, cam)
+        fb, sl, cnt = sc.render_pt(H, cam, w, h, it, math_mode=1, fb=fb, want_samples=True, threads=8)
+        for k in tot:
+            tot[k] += cnt[k]
+        got_sl = pt.sample_radiance()[: w * h * 16]
+        bad = np.nonzero((got_sl != sl).any(axis=1))[0]
+        assert len(bad) == 0, "iteration %d: %d samples differ, first %s: %s vs %s" % (it, len(bad), bad[:5], got_sl[bad[:2]], sl[bad[:2]])
+    got = pt.read_framebuffer()[: w * h]
+    assert np.array_equal(got, fb)
+    assert pt.getSteps() == iters
+    st = pt.stats()
+    for k in tot:
+        assert st[k] == tot[k], (k, st[k], tot[k])
+    # resolve
+    u8 = pt.toImageAsync(None)
+    mv.synchronize()
+    assert np.array_equal(u8[: w * h], O.resolve(fb, math_mode=1))
+    assert tot["rays"] > tot["samples"]  # secondary rays were traced
+
+
+def test_path_tracer_no_emission_and_no_hdri(mv, O, bunny256, hdr):
+    rgba, hw, hh = hdr
+    w, h = 96, 64
+    cam = probe_camera(bunny256.origin, bunny256.dps, 256, focus=9.0, lens_r=0.0)
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    # (a) white bunny, no emissive voxels: no extra rays (voxKernel.cu:721)
+    pt = make_pt(mv, O, bunny256, w, h, rgba, hw, hh)
+    pt.step(None, cam)
+    fb, _, cnt = bunny256.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
+    assert np.array_equal(pt.read_framebuffer()[: w * h], fb)
+    assert pt.stats()["rays"] == cnt["rays"]
+    # (b) HDRI disabled (m_scale <= 0, renderCommon.hpp:467-470): no shadow rays at all
+    pt2 = make_pt(mv, O, bunny256, w, h, rgba, hw, hh, hdri_scale=0.0)
+    pt2.step(None, cam)
+    H.set_scale(0.0)
+    fb2, _, cnt2 = bunny256.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
+    assert np.array_equal(pt2.read_framebuffer()[: w * h], fb2)
+    st = pt2.stats()
+    assert st["shadowRays"] == 0 == cnt2["shadowRays"] and st["rays"] == cnt2["rays"]
+
+
+def test_tile_split_reproduces_single_gpu_image(mv, O, bunny256_color, hdr):
+    """3 'ranks' on one GPU: owned tiles rendered separately, assembled on the device, equal the 1-rank frame"""
+    from massivevoxelraytracing_amd import tiles
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h, n = 200, 113, 3
+    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
+    full = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    full.step(None, cam)
+    want = full.read_framebuffer()[: w * h]
+    owned = tiles.owned_pixels(w, h, n)
+    parts = []
+    for r in range(n):
+        pt = make_pt(mv, O, sc, w, h, rgba, hw, hh, tile=(r, n))
+        assert pt.owned_pixels() == owned
+        pt.step(None, cam)
+        parts.append(pt.read_framebuffer())
+    gathered = np.stack(parts)
+    assert np.array_equal(tiles.assemble(gathered, w, h), want)
+    d_g = mv.DeviceArray.from_host(gathered)
+    d_f = mv.DeviceArray((w * h, 4), np.float32)
+    mv.assemble_tiles(d_g, n, owned, w, h, d_f)
+    mv.synchronize()
+    assert np.array_equal(d_f.to_host(), want)
+
+
+def test_full_hd_frame_properties(mv, O, bunny256_color, hdr):
+    """BASELINE frame size (1920x1080, one 16-spp step): size-independent properties + an oracle band"""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h = 1920, 1080
+    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
+    pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    pt.step(None, cam)
+    fb = pt.read_framebuffer()
+    assert np.isfinite(fb).all() and (fb[:, :3] >= 0).all()
+    assert (fb[:, 3] == 16.0).all()
+    st = pt.stats()
+    assert st["samples"] == w * h * 16
+    assert st["samples"] <= st["rays"] <= 18 * st["samples"]  # ray budget, voxKernel.cu:675,691-760
+    # a band of 8192 pixels through the bunny, bit-exact against the oracle
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    p0 = 600 * w + 512
+    ref = np.zeros((w * h, 4), np.float32)
+    sc.render_pt(H, cam, w, h, 0, math_mode=1, fb=ref, pixel_begin=p0, pixel_end=p0 + 8192, threads=8)
+    assert np.array_equal(fb[p0:p0 + 8192], ref[p0:p0 + 8192])
+    # idempotence of clear + re-render (deterministic accumulation order)
+    pt.clearFrameBuffer(None)
+    assert pt.getSteps() == 0
+    pt.step(None, cam)
+    assert np.array_equal(pt.read_framebuffer(), fb)
+
+
+def test_libm_vs_detmath_image_tolerance(O, bunny256_color, hdr):
+    """The oracle in the reference's HOST math (libm) vs the deterministic math the GPU uses:
+    mean radiance within 1e-3 relative on a 128x72x16spp frame (chaotic per-path divergence averages out)."""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h = 128, 72
+    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
+    a, _, _ = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, 0), cam, w, h, 0, math_mode=0, threads=8)
+    b, _, _ = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, 1), cam, w, h, 0, math_mode=1, threads=8)
+    ma, mb = a[:, :3].astype(np.float64).mean(0), b[:, :3].astype(np.float64).mean(0)
+    assert np.abs(ma - mb).max() / ma.max() < 1e-3
+    same = (a == b).all(axis=1).mean()
+    assert same > 0.95
