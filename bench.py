@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): wavefront path tracing of a sparse voxel
+octree at 1920x1080, 64 spp (4 steps of 16 spp), reported as Mrays/s (primary + secondary rays).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid-res R] [--scene dragon|rtcamp]
+
+A "step" is one PathTracer::step (reference PathTracer.hpp:150-169): 16 spp for every pixel of the frame.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's 256-pixel blocks are dealt
+round-robin to the ranks (strong scaling: the total work is fixed), the read-only SVO is rebuilt
+identically on every rank, and after the K steps the per-rank accumulation buffers are exchanged with ONE
+RCCL all-gather and assembled into the full frame -- all inside the timed region.
+
+Timed region: inputs resident in HBM (scene built, HDRI/PMJ tables uploaded, buffers allocated) before it
+starts; K steps (+ gather for N > 1) between barrier + device synchronize on both sides; max over ranks.
+
+The JSON line also carries
+  roofline     -- traversal kernel (kPtTrace): algorithmic bytes per launch / mean launch time, both measured
+                  in the timed region (HIP events on the launch stream), against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's voxRT / renderPT arithmetic, oracle/) timed on this
+                  host's cores on a bounded band of the same frame (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid-res", type=int, default=2048)
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "rtcamp"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811  (device memory for the collective + torch.distributed over RCCL)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import massivevoxelraytracing_amd as mv
+    from massivevoxelraytracing_amd import scenes, tiles
+    mv.lib()
+    mv.set_device(local_rank)
+
+    def barrier_sync():
+        mv.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- scene + renderer (outside the timed region) ----
+    t_setup = time.time()
+    verts, cols, emis = (scenes.dragon_standin if args.scene == "dragon" else scenes.rtcamp_standin)(args.detail)
+    origin, dps = scenes.bounding_grid(verts, args.grid_res)
+    W, H = args.width, args.height
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.set_tile(rank, world)
+    pt.resizeFrameBufferIfNeeded(None, W, H)
+    hdr = os.path.join(ROOT, "tests", "golden", "monks_forest_s.hdr")
+    pt.loadHDRI(None, hdr, hdr)
+    t_build = time.time()
+    pt.updateScene(verts, cols, emis, None, origin, dps, args.grid_res)
+    mv.synchronize()
+    build_s = time.time() - t_build
+    info = pt.m_intersectorOctreeGPU.info()
+    lo, hi = np.array(info.lower[:]), np.array(info.upper[:])
+    centre = (lo + hi) / 2
+    if args.scene == "dragon":
+        eye = centre + np.array([2.6, 1.5, 3.1])
+    else:
+        eye = centre + np.array([4.2, 2.2, 5.0])
+    focus = float(np.linalg.norm(eye - centre))
+    cam = scenes.look_at_camera(eye, centre, 40.0, focus, 0.02)
+    setup_s = time.time() - t_setup
+
+    owned = pt.owned_pixels()
+    gather_in = gather_out = frame = None
+    if dist is not None:
+        gather_in = torch.empty(owned * 4, dtype=torch.float32, device="cuda")
+        gather_out = torch.empty(world * owned * 4, dtype=torch.float32, device="cuda")
+        frame = torch.empty(W * H * 4, dtype=torch.float32, device="cuda")
+
+    def run_steps(k):
+        for _ in range(k):
+            pt.step(None, cam)
+        if dist is not None:
+            mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16)
+            mv.synchronize()  # the copy ran on the null stream; RCCL uses torch's stream
+            dist.all_gather_into_tensor(gather_out, gather_in)
+            torch.cuda.current_stream().synchronize()
+            mv.assemble_tiles(gather_out, world, owned, W, H, frame)
+
+    # ---- warmup, then the timed region ----
+    run_steps(args.warmup)
+    pt.clearFrameBuffer(None)
+    pt.reset_stats()
+    pt.set_profiling(True)
+    barrier_sync()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    st = pt.stats()
+    pt.set_profiling(False)
+
+    rays = float(st["rays"])
+    if dist is not None:
+        t = torch.tensor([elapsed, rays], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays = float(t[1])
+
+    # ---- roofline of the traversal kernel (DESIGN.md "Algorithmic bytes") ----
+    # B_ray = 28 (ray in) + 12 (hit out) + D * (4 + 4 [non-shadow]) + 8 [non-shadow hit]   
+    algo_bytes = st["rays"] * 40 + st["descents"] * 8 + st["shadowDescents"] * 4 + st["hits"] * 8
+    launches = max(int(st["traceLaunches"]), 1)
+    trace_ms = st["traceKernelMs"]
+    roofline = None
+    if trace_ms > 0:
+        achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "kPtTrace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": int(algo_bytes / launches), "avg_launch_ms": round(trace_ms / launches, 4), "launches": launches,
+            "bytes_per_ray": round(algo_bytes / max(st["rays"], 1), 2),
+            "descents_per_ray": round((st["descents"] + st["shadowDescents"]) / max(st["rays"], 1), 2),
+            "trace_share_of_step_time": round(trace_ms / max(st["totalKernelMs"], 1e-9), 3),
+            "trace_kernel_mrays_per_s": round(st["rays"] / (trace_ms * 1e-3) / 1e6, 1),
+        }
+
+    # ---- CPU baseline (rank 0, single GPU runs only): the oracle on a bounded band of the same frame ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O  # the checker / baseline -- never part of the measured GPU path
+        nodes, attrs, _ = pt.m_intersectorOctreeGPU.download()
+        sc = O.Scene(nodes.view(O.NODE_DTYPE), attrs, origin, dps, args.grid_res, info.hasEmission)
+        rgba, hw, hh = O.decode_rgbe(open(hdr, "rb").read())
+        Hh = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+        cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+        rows = args.cpu_rows or max(8, min(H, int(H * 0.25)))
+        y0 = (H - rows) // 2
+        p0, p1 = y0 * W, (y0 + rows) * W
+        fb_cpu = np.zeros((W * H, 4), np.float32)
+        tc = time.perf_counter()
+        _, _, cnt = sc.render_pt(Hh, cam, W, H, 0, math_mode=1, fb=fb_cpu, pixel_begin=p0, pixel_end=p1, threads=cores)
+        cpu_s = time.perf_counter() - tc
+        # the same band from the GPU frame buffer (iteration 0 only) must agree bit for bit
+        pt.clearFrameBuffer(None)
+        pt.step(None, cam)
+        gpu_band = pt.read_framebuffer()[p0:p1]
+        cpu = {
+            "value": round(cnt["rays"] / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "rows %d-%d of the %dx%d frame, iteration 0 (16 spp): %d samples, %d rays in %.1f s" % (y0, y0 + rows - 1, W, H, cnt["samples"], cnt["rays"], cpu_s),
+            "gpu_band_bit_exact": bool(np.array_equal(gpu_band, fb_cpu[p0:p1])),
+        }
+
+    if rank == 0:
+        spp = 16 * args.steps
+        out = {
+            "metric": "Mrays/sec (primary+secondary) at %dx%d, %d spp" % (W, H, spp),
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s stand-in %d^3 SVO (procedural, seeded), wavefront path trace %dx%d, %d spp = %d steps x 16, 8 bounces + IBL shadow rays" %
+                            ("xyzrgb_dragon" if args.scene == "dragon" else "rtcamp9", args.grid_res, W, H, spp, args.steps),
+                "voxels": int(info.numberOfVoxels), "dag_nodes": int(info.numberOfNodes), "octree_mb": round(info.numberOfNodes * 64 / 1e6, 1),
+                "triangles": int(len(verts) // 3), "svo_build_s": round(build_s, 3), "setup_s": round(setup_s, 1),
+                "parallelism": "tile-split x%d (256-px blocks round-robin) + 1 RCCL all-gather" % world if world > 1 else "1 GPU",
+                "rays_per_sample": round(rays / max(st["samples"] * (world if world > 1 else 1), 1), 3) if world == 1 else None,
+                "device": mv.device_name(),
+            },
+            "rays": int(rays),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

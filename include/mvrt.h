@@ -48,6 +48,7 @@ int mvrt_malloc( void** dev, uint64_t bytes );
 int mvrt_free( void* dev );
 int mvrt_memcpy_h2d( void* dev, const void* host, uint64_t bytes, void* stream );
 int mvrt_memcpy_d2h( void* host, const void* dev, uint64_t bytes, void* stream );
+int mvrt_memcpy_d2d( void* dstDev, const void* srcDev, uint64_t bytes, void* stream ); /* asynchronous on stream */
 
 /* ---- IntersectorOctreeGPU ------------------------------------------------------------------ */
 typedef struct mvrt_svo_info
@@ -177,7 +178,7 @@ typedef struct mvrt_pt_stats
 	double shadeKernelMs;	 /* summed time of shade+compact kernels (profiling on) */
 	double totalKernelMs;	 /* summed time of every kernel of step() (profiling on) */
 } mvrt_pt_stats;
-int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled ); /* HIP events around each kernel of step(); costs a sync per step */
+int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled ); /* HIP events on `stream` around each kernel of step(); read by get_stats */
 int mvrt_pt_reset_stats( mvrt_pt* pt );
 int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out ); /* synchronises the stream */
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mvrt_free": (_i32, [_vp]),
     "mvrt_memcpy_h2d": (_i32, [_vp, _vp, _u64, _vp]),
     "mvrt_memcpy_d2h": (_i32, [_vp, _vp, _u64, _vp]),
+    "mvrt_memcpy_d2d": (_i32, [_vp, _vp, _u64, _vp]),
     "mvrt_svo_create": (_i32, [_vp]),
     "mvrt_svo_destroy": (_i32, [_vp]),
     "mvrt_svo_build": (_i32, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _f32, _i32]),
@@ -432,6 +433,10 @@ class PathTracer:
         s = PtStats()
         _check(lib().mvrt_pt_get_stats(self._h, stream, C.byref(s)))
         return {k: getattr(s, k) for k, _ in PtStats._fields_}
+
+
+def memcpy_d2d(dst_dev, src_dev, nbytes, stream=None):
+    _check(lib().mvrt_memcpy_d2d(_dev_ptr(dst_dev), _dev_ptr(src_dev), nbytes, stream))
 
 
 def assemble_tiles(gathered_dev, tile_count, rank_stride_pixels, width, height, frame_dev, stream=None):

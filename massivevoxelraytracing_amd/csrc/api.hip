@@ -91,6 +91,11 @@ MVRT_EXPORT int mvrt_memcpy_h2d( void* dev, const void* host, uint64_t bytes, vo
 	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
 	return 0;
 }
+MVRT_EXPORT int mvrt_memcpy_d2d( void* dstDev, const void* srcDev, uint64_t bytes, void* stream )
+{
+	MVRT_HIP( hipMemcpyAsync( dstDev, srcDev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream ) );
+	return 0;
+}
 MVRT_EXPORT int mvrt_memcpy_d2h( void* host, const void* dev, uint64_t bytes, void* stream )
 {
 	MVRT_HIP( hipMemcpyAsync( host, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream ) );
@@ -808,13 +813,7 @@ MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] 
 	f.iteration = pt->steps++; // PathTracer.hpp:159
 	int rc = launchPtStep( pt->intersector->dev(), pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, pt->buf, pt->fbF32.as<float4>(), pt->numCUs,
 						   pt->profiling ? &pt->prof : nullptr, (hipStream_t)stream );
-	if( rc ) return rc;
-	if( pt->profiling )
-	{
-		MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
-		pt->prof.collect();
-	}
-	return 0;
+	return rc; // profiling events are collected lazily by mvrt_pt_get_stats (no sync inside step)
 }
 MVRT_EXPORT int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], const float proj[16], float focus, float lensR )
 {

@@ -1,0 +1,128 @@
+"""GPU SVO construction (mvrt_svo_build = IntersectorOctreeGPU::build) against the oracle's CPU builder
+(voxelize -> mergeVoxels -> buildOctreeDAGReference -> embedMasks).  Bar: the voxel list, the
+attributes AND the node array are bit-identical -- node numbering included (the reference's own GPU
+builder numbers DAG nodes racily; ours reproduces the CPU reference's creation order)."""
+import numpy as np
+import pytest
+
+from common import bunny_tris, golden, hdr_bytes, position_colors, probe_camera
+
+pytestmark = pytest.mark.gpu
+G = golden()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def mv():
+    import massivevoxelraytracing_amd as m
+    m.lib()
+    return m
+
+
+def gpu_build(mv, tris, res, cols=None, emis=None):
+    from massivevoxelraytracing_amd import scenes
+    v = tris.reshape(-1, 3)
+    origin, dps = scenes.bounding_grid(v, res)
+    svo = mv.IntersectorOctreeGPU()
+    svo.build(v, None if cols is None else cols.reshape(-1, 3), None if emis is None else emis.reshape(-1, 3), None, origin, dps, res)
+    return svo, origin, dps
+
+
+def assert_same_svo(O, mv, svo, sc):
+    info = svo.info()
+    assert info.totalDumpedVoxels == sc.dumped
+    assert info.numberOfVoxels == len(sc.morton)
+    assert info.numberOfNodes == len(sc.nodes)
+    assert info.hasEmission == sc.has_emission
+    assert np.array_equal(np.array(info.lower[:], np.float32), sc.bounds()[0])
+    assert np.array_equal(np.array(info.upper[:], np.float32), sc.bounds()[1])
+    nodes, attrs, morton = svo.download(want_morton=True)
+    assert np.array_equal(morton, sc.morton)
+    assert np.array_equal(attrs, sc.attrs)
+    want = sc.nodes.copy()
+    want["_pad"] = 0
+    got = nodes.view(O.NODE_DTYPE).copy()
+    got["_pad"] = 0
+    assert np.array_equal(got["mask"], want["mask"])
+    assert np.array_equal(got["children"], want["children"])
+    assert np.array_equal(got["psum"], want["psum"])
+
+
+def test_bunny256_build_matches_golden_and_oracle(mv, O):
+    tris = bunny_tris()
+    svo, origin, dps = gpu_build(mv, tris, 256)
+    g = G["bunny"]["256"]
+    info = svo.info()
+    assert (info.totalDumpedVoxels, info.numberOfVoxels, info.numberOfNodes) == (g["dumped"], g["voxels"], g["dag_nodes"])
+    assert np.float32(dps) == np.float32(G["bunny"]["dps_256"])
+    assert_same_svo(O, mv, svo, O.build_scene_from_triangles(tris, 256))
+    # and the built octree traces like the golden
+    cam = probe_camera(origin, dps, 256)
+    r = svo.render(cam, 1920, 1080)
+    assert int((r["t"] != O.MAX_FLOAT).sum()) == g["primary_1080p"]["hits"]
+
+
+def test_bunny_with_attributes_and_emission(mv, O):
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    svo, _, _ = gpu_build(mv, tris, 128, cols, emis)
+    sc = O.build_scene_from_triangles(tris, 128, cols, emis)
+    assert sc.has_emission == 1
+    assert_same_svo(O, mv, svo, sc)
+
+
+def test_bunny1024_build(mv, O):
+    tris = bunny_tris()
+    svo, _, _ = gpu_build(mv, tris, 1024)
+    g = G["bunny"]["1024"]
+    info = svo.info()
+    assert (info.totalDumpedVoxels, info.numberOfVoxels, info.numberOfNodes) == (g["dumped"], g["voxels"], g["dag_nodes"])
+    assert_same_svo(O, mv, svo, O.build_scene_from_triangles(tris, 1024))
+
+
+def test_procedural_scene_build(mv, O):
+    from massivevoxelraytracing_amd import scenes
+    v, c, e = scenes.dragon_standin(0.25)
+    svo, _, _ = gpu_build(mv, v, 512, c, e)
+    sc = O.build_scene_from_triangles(v.reshape(-1, 9), 512, c.reshape(-1, 9), e.reshape(-1, 9))
+    assert_same_svo(O, mv, svo, sc)
+
+
+def test_tiny_and_degenerate_inputs(mv, O):
+    one = np.array([[0.1, 0.2, 0.3, 0.9, 0.25, 0.35, 0.4, 0.8, 0.7]], np.float32)
+    for res in (2, 4, 32):
+        svo = mv.IntersectorOctreeGPU()
+        svo.build(one.reshape(-1, 3), None, None, None, np.zeros(3, np.float32), np.float32(1.0 / res), res)
+        sc = O.build_scene_from_triangles(one, res, origin=np.zeros(3, np.float32), dps=np.float32(1.0 / res))
+        assert_same_svo(O, mv, svo, sc)
+    svo = mv.IntersectorOctreeGPU()
+    with pytest.raises(mv.MvrtError, match="power of two"):  # IntersectorOctreeGPU.hpp:48-51 aborts
+        svo.build(one.reshape(-1, 3), None, None, None, np.zeros(3, np.float32), 0.01, 100)
+    with pytest.raises(mv.MvrtError, match="touch no voxel"):
+        svo.build(one.reshape(-1, 3) + 50.0, None, None, None, np.zeros(3, np.float32), np.float32(1 / 32), 32)
+
+
+def test_update_scene_then_step_matches_oracle(mv, O):
+    """PathTracer::updateScene -> step, the call order of voxPTGPU.cpp:169-189"""
+    from massivevoxelraytracing_amd import scenes
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    origin, dps = scenes.bounding_grid(tris.reshape(-1, 3), 256)
+    rgba, hw, hh = O.decode_rgbe(hdr_bytes())
+    w, h = 160, 90
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    pt.loadHDRIPixels(None, rgba, hw, hh, rgba, hw, hh)
+    pt.updateScene(tris.reshape(-1, 3), cols.reshape(-1, 3), emis.reshape(-1, 3), None, origin, dps, 256)
+    cam = probe_camera(origin, dps, 256, focus=9.0, lens_r=0.05)
+    pt.step(None, cam)
+    sc = O.build_scene_from_triangles(tris, 256, cols, emis)
+    want, _, _ = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, 1), cam, w, h, 0, math_mode=1, threads=8)
+    assert np.array_equal(pt.read_framebuffer()[: w * h], want)
+    assert pt.getNumberOfVoxels() == len(sc.morton) and pt.getOctreeBytes() == len(sc.nodes) * 68

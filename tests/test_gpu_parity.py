@@ -271,18 +271,3 @@ def test_full_hd_frame_properties(mv, O, bunny256_color, hdr):
     assert pt.getSteps() == 0
     pt.step(None, cam)
     assert np.array_equal(pt.read_framebuffer(), fb)
-
-
-def test_libm_vs_detmath_image_tolerance(O, bunny256_color, hdr):
-    """The oracle in the reference's HOST math (libm) vs the deterministic math the GPU uses:
-    mean radiance within 1e-3 relative on a 128x72x16spp frame (chaotic per-path divergence averages out)."""
-    rgba, hw, hh = hdr
-    sc = bunny256_color
-    w, h = 128, 72
-    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
-    a, _, _ = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, 0), cam, w, h, 0, math_mode=0, threads=8)
-    b, _, _ = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, 1), cam, w, h, 0, math_mode=1, threads=8)
-    ma, mb = a[:, :3].astype(np.float64).mean(0), b[:, :3].astype(np.float64).mean(0)
-    assert np.abs(ma - mb).max() / ma.max() < 1e-3
-    same = (a == b).all(axis=1).mean()
-    assert same > 0.95
