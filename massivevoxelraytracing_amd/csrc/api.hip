@@ -135,6 +135,8 @@ struct mvrt_svo
 	uint8_t* masks = nullptr;
 	uint2* attrs = nullptr;
 	uint64_t* morton = nullptr; // only after build()
+	mutable DevBuf wsBuf;		// traversal workspace (spill rows + cursor), sized on demand
+	mutable TraceWorkspace ws = { nullptr, 0, nullptr };
 	mvrt_svo_info info;
 	uint8_t rootMask = 0;
 	mvrt_svo()
@@ -155,6 +157,20 @@ struct mvrt_svo
 		float es = info.emissionScale;
 		memset( &info, 0, sizeof( info ) );
 		info.emissionScale = es;
+	}
+	int ensureWorkspace() const // one per handle; users of one handle must be stream-ordered
+	{
+		const uint64_t lanes = traceWorkspaceLanes();
+		const uint64_t levels = info.levels ? info.levels : 1;
+		const uint64_t bytes = 256 + levels * lanes * sizeof( uint4 );
+		if( wsBuf.bytes < bytes )
+		{
+			if( wsBuf.alloc( bytes ) ) return 1;
+		}
+		ws.cursor = (unsigned long long*)wsBuf.p;
+		ws.spill = (uint4*)( (uint8_t*)wsBuf.p + 256 );
+		ws.spillStride = lanes;
+		return 0;
 	}
 	SvoDev dev() const
 	{
@@ -302,7 +318,8 @@ MVRT_EXPORT int mvrt_trace_batch( const mvrt_svo* svo, uint64_t n, const float* 
 {
 	REQUIRE( svo && svo->nodes, "mvrt_trace_batch: no octree (build or upload first)" );
 	REQUIRE( tDev, "mvrt_trace_batch: t output is required" );
-	return launchTraceBatch( svo->dev(), n, roxDev, royDev, rozDev, rdxDev, rdyDev, rdzDev, isShadowDev, tDev, nMajorDev, vIndexDev, descentsDev, (hipStream_t)stream );
+	if( svo->ensureWorkspace() ) return 1;
+	return launchTraceBatch( svo->dev(), svo->ws, n, roxDev, royDev, rozDev, rdxDev, rdyDev, rdzDev, isShadowDev, tDev, nMajorDev, vIndexDev, descentsDev, (hipStream_t)stream );
 }
 
 MVRT_EXPORT int mvrt_trace_batch_host( const mvrt_svo* svo, uint64_t n, const float* roHost, const float* rdHost, const uint8_t* isShadowHost, float* tHost,
@@ -326,7 +343,8 @@ MVRT_EXPORT int mvrt_trace_batch_host( const mvrt_svo* svo, uint64_t n, const fl
 		MVRT_HIP( hipMemcpy( sh.p, isShadowHost, n, hipMemcpyHostToDevice ) );
 	}
 	const float* b = in.as<float>();
-	if( launchTraceBatch( svo->dev(), n, b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, isShadowHost ? sh.as<uint8_t>() : nullptr, t.as<float>(), nm.as<int32_t>(),
+	if( svo->ensureWorkspace() ) return 1;
+	if( launchTraceBatch( svo->dev(), svo->ws, n, b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, isShadowHost ? sh.as<uint8_t>() : nullptr, t.as<float>(), nm.as<int32_t>(),
 						  vi.as<uint32_t>(), de.as<uint32_t>(), 0 ) )
 		return 1;
 	MVRT_HIP( hipDeviceSynchronize() );
@@ -349,7 +367,8 @@ MVRT_EXPORT int mvrt_render_primary( const mvrt_svo* svo, const float camera[15]
 {
 	REQUIRE( svo && svo->nodes, "mvrt_render_primary: no octree" );
 	REQUIRE( width > 0 && height > 0, "bad resolution %dx%d", width, height );
-	return launchRenderPrimary( svo->dev(), cameraFrom15( camera ), width, height, showVertexColor, (uchar4*)rgbaDev, tDev, nMajorDev, vIndexDev, descentsDev,
+	if( svo->ensureWorkspace() ) return 1;
+	return launchRenderPrimary( svo->dev(), svo->ws, cameraFrom15( camera ), width, height, showVertexColor, (uchar4*)rgbaDev, tDev, nMajorDev, vIndexDev, descentsDev,
 								(hipStream_t)stream );
 }
 
@@ -660,7 +679,7 @@ static int allocWork( mvrt_pt* pt )
 	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays, 4 bytes each;
 	// 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
 	const uint64_t words = cap * ( 32 + 6 + 3 + 3 );
-	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 16 * 8 + 64 * 256;
+	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 64 * 256;
 	if( pt->work.alloc( bytes ) ) return 1;
 	uint8_t* base = (uint8_t*)pt->work.p;
 	uint64_t off = 0;
@@ -686,6 +705,7 @@ static int allocWork( mvrt_pt* pt )
 	b.hitE = (uint8_t*)take( cap );
 	b.blockCount = (uint32_t*)take( nBlocks * 4 );
 	b.liveCount = (uint32_t*)take( 64 * 4 );
+	b.cursors = (unsigned long long*)take( 16 * 8 );
 	b.stats = (unsigned long long*)take( 16 * 8 );
 	b.cap = cap;
 	MVRT_HIP( hipMemset( b.liveCount, 0, 64 * 4 ) );
@@ -811,7 +831,8 @@ MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] 
 	f.ownedPixels = pt->ownedPixels;
 	f.validOwnedPixels = pt->validOwnedPixels;
 	f.iteration = pt->steps++; // PathTracer.hpp:159
-	int rc = launchPtStep( pt->intersector->dev(), pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, pt->buf, pt->fbF32.as<float4>(), pt->numCUs,
+	if( pt->intersector->ensureWorkspace() ) return 1;
+	int rc = launchPtStep( pt->intersector->dev(), pt->intersector->ws, pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, pt->buf, pt->fbF32.as<float4>(), pt->numCUs,
 						   pt->profiling ? &pt->prof : nullptr, (hipStream_t)stream );
 	return rc; // profiling events are collected lazily by mvrt_pt_get_stats (no sync inside step)
 }

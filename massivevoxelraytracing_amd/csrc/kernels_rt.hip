@@ -3,8 +3,11 @@
 //
 // Reference semantics (what each kernel must reproduce): /root/reference/voxKernel.cu:437-483 (render),
 // :610-777 (renderPT), voxCommon.hpp:231-423 (traversal), StreamCompaction.hpp:87-184 (stable compaction).
+#include <stdlib.h>
+
 #include "launch.h"
 #include "traverse.h"
+#include "traverse_stream.h"
 
 #define WAVE 64
 #define TRACE_BLOCK 64 // one wavefront per workgroup: no barriers, LDS granule = one wave's stack
@@ -16,6 +19,107 @@ MVRT_DI unsigned long long waveSum( unsigned long long v )
 	for( int o = 32; o > 0; o >>= 1 ) v += __shfl_down( v, o, WAVE );
 	return v;
 }
+
+static int numCUs();
+
+// =====================================================================================================
+// Persistent-wave ("stream") variants for embedded-mask octrees: traverse_stream.h
+// =====================================================================================================
+#define STREAM_WAVES_PER_CU 32
+
+struct BatchIO
+{
+	const float *rox, *roy, *roz, *rdx, *rdy, *rdz;
+	const uint8_t* isShadow;
+	float* tOut;
+	int32_t* nMajorOut;
+	uint32_t* vIndexOut;
+	uint32_t* descentsOut;
+	MVRT_DI bool load( uint64_t i, f3* ro, f3* rd ) const
+	{
+		*ro = mk3( rox[i], roy[i], roz[i] );
+		*rd = mk3( rdx[i], rdy[i], rdz[i] );
+		return isShadow ? isShadow[i] != 0 : false;
+	}
+	MVRT_DI void store( uint64_t i, const StreamHit& h, bool ) const
+	{
+		tOut[i] = h.t;
+		if( nMajorOut ) nMajorOut[i] = h.nMajor;
+		if( vIndexOut ) vIndexOut[i] = h.vIndex;
+		if( descentsOut ) descentsOut[i] = h.descents;
+	}
+};
+__global__ void __launch_bounds__( 64 ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
+{
+	__shared__ uint4 ring[MVRT_RING * 64];
+	traceStream( svo, io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+}
+
+struct PrimaryIO
+{
+	SvoDev svo;
+	CameraPinhole cam;
+	int W, H, showVertexColor;
+	uchar4* rgba;
+	float* tOut;
+	int32_t* nMajorOut;
+	uint32_t* vIndexOut;
+	uint32_t* descentsOut;
+	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
+	MVRT_DI bool load( uint64_t pixelIdx, f3* ro, f3* rd )
+	{
+		int x = (int)( pixelIdx % W );
+		int y = (int)( pixelIdx / W );
+		cameraShoot( cam, ro, rd, x, y, 0.5f, 0.5f, W, H ); // voxKernel.cu:455
+		rdKeep = *rd;
+		return false;
+	}
+	MVRT_DI void store( uint64_t pixelIdx, const StreamHit& r, bool ) const
+	{
+		uchar4 c = make_uchar4( 0, 0, 0, 255 );
+		if( r.t != MVRT_MAXF ) // voxKernel.cu:462-478
+		{
+			if( showVertexColor )
+			{
+				uint32_t col = svo.attrs[r.vIndex].x;
+				c = make_uchar4( col & 0xFF, ( col >> 8 ) & 0xFF, ( col >> 16 ) & 0xFF, ( col >> 24 ) & 0xFF );
+			}
+			else
+			{
+				f3 hn = getHitN( r.nMajor, rdKeep );
+				f3 color = ( hn + mk3( 1.0f, 1.0f, 1.0f ) ) * 0.5f;
+				c = make_uchar4( (uint8_t)( 255 * color.x + 0.5f ), (uint8_t)( 255 * color.y + 0.5f ), (uint8_t)( 255 * color.z + 0.5f ), 255 );
+			}
+		}
+		if( rgba ) rgba[pixelIdx] = c;
+		if( tOut ) tOut[pixelIdx] = r.t;
+		if( nMajorOut ) nMajorOut[pixelIdx] = r.nMajor;
+		if( vIndexOut ) vIndexOut[pixelIdx] = r.vIndex;
+		if( descentsOut ) descentsOut[pixelIdx] = r.descents;
+	}
+};
+__global__ void __launch_bounds__( 64 ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
+{
+	__shared__ uint4 ring[MVRT_RING * 64];
+	traceStream( io.svo, io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+}
+
+static uint32_t streamChunk( uint64_t total, uint64_t waves )
+{
+	uint64_t c = total / ( waves * 4 );
+	c = ( c + 63 ) / 64 * 64;
+	if( c < 64 ) c = 64;
+	if( c > 1024 ) c = 1024;
+	return (uint32_t)c;
+}
+static int streamGrid( uint64_t total, int nCUs )
+{
+	uint64_t need = ( total + 63 ) / 64;
+	uint64_t cap = (uint64_t)nCUs * STREAM_WAVES_PER_CU;
+	if( need < 1 ) need = 1;
+	return (int)( need < cap ? need : cap );
+}
+uint64_t traceWorkspaceLanes() { return (uint64_t)numCUs() * STREAM_WAVES_PER_CU * 64; }
 
 // =====================================================================================================
 // mvrt_trace_batch: host-callable batch form of IntersectorOctreeGPU::intersect
@@ -47,6 +151,13 @@ __global__ void __launch_bounds__( TRACE_BLOCK ) kTraceBatch( SvoDev svo, uint64
 static size_t traceLdsBytes( const SvoDev& svo, int block )
 {
 	uint32_t slots = svo.levels < 1 ? 1 : svo.levels;
+	static int pad = -1; // MVRT_LDS_PAD_SLOTS: occupancy experiments only (extra, unused stack slots)
+	if( pad < 0 )
+	{
+		const char* e = getenv( "MVRT_LDS_PAD_SLOTS" );
+		pad = e ? atoi( e ) : 0;
+	}
+	slots += pad;
 	return (size_t)slots * MVRT_STACK_FIELDS * block * sizeof( uint32_t );
 }
 
@@ -81,10 +192,19 @@ static int allowLds( K kernel, size_t bytes )
 	return 0;
 }
 
-int launchTraceBatch( const SvoDev& svo, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy, const float* rdz,
-					  const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
+int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy,
+					  const float* rdz, const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
 {
 	if( n == 0 ) return 0;
+	if( svo.embedded && ws.spill )
+	{
+		BatchIO io = { rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, vIndex, descents };
+		int grid = streamGrid( n, numCUs() );
+		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
+		hipLaunchKernelGGL( kTraceBatchStream, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		MVRT_HIP( hipGetLastError() );
+		return 0;
+	}
 	size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
 	if( allowLds( kTraceBatch, lds ) ) return 1;
 	int grid = persistentGrid( n, TRACE_BLOCK, numCUs(), 32 );
@@ -137,11 +257,31 @@ __global__ void __launch_bounds__( TRACE_BLOCK ) kRenderPrimary( SvoDev svo, Cam
 	}
 }
 
-int launchRenderPrimary( const SvoDev& svo, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t, int32_t* nMajor, uint32_t* vIndex,
-						 uint32_t* descents, hipStream_t stream )
+int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t,
+						 int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
 {
 	uint64_t n = (uint64_t)W * H;
 	if( n == 0 ) return 0;
+	if( svo.embedded && ws.spill )
+	{
+		PrimaryIO io;
+		io.svo = svo;
+		io.cam = cam;
+		io.W = W;
+		io.H = H;
+		io.showVertexColor = showVertexColor;
+		io.rgba = rgba;
+		io.tOut = t;
+		io.nMajorOut = nMajor;
+		io.vIndexOut = vIndex;
+		io.descentsOut = descents;
+		io.rdKeep = mk3( 0, 0, 0 );
+		int grid = streamGrid( n, numCUs() );
+		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
+		hipLaunchKernelGGL( kRenderPrimaryStream, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		MVRT_HIP( hipGetLastError() );
+		return 0;
+	}
 	size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
 	if( allowLds( kRenderPrimary, lds ) ) return 1;
 	int grid = persistentGrid( n, TRACE_BLOCK, numCUs(), 32 );
@@ -302,6 +442,7 @@ __global__ void __launch_bounds__( 256 ) kPtGenerate( PtParams P )
 	if( blockIdx.x == 0 && threadIdx.x == 0 )
 	{
 		P.buf.liveCount[0] = (uint32_t)n;
+		for( int k = 0; k < 16; k++ ) P.buf.cursors[k] = 0ull; // per-stage ray cursors of the persistent traversal waves
 		atomicAdd( &P.buf.stats[5], (unsigned long long)n );
 	}
 }
@@ -361,6 +502,81 @@ __global__ void __launch_bounds__( TRACE_BLOCK ) kPtTrace( PtParams P, int stage
 		if( dNormal ) atomicAdd( &P.buf.stats[2], dNormal );
 		if( dShadow ) atomicAdd( &P.buf.stats[3], dShadow );
 		if( nHits ) atomicAdd( &P.buf.stats[4], nHits );
+	}
+}
+
+struct PtIO
+{
+	PtBuffers buf;
+	const PathSet* in;
+	uint64_t n;
+	int shadowKind;
+	unsigned long long dNormal, dShadow, nHits;
+	MVRT_DI int kindOf( uint64_t r, uint64_t* i ) const
+	{
+		int kindSlot = ( r >= n ) + ( r >= 2 * n );
+		*i = r - (uint64_t)kindSlot * n;
+		return kindSlot == 0 ? 0 : ( kindSlot == 1 ? ( shadowKind ? 1 : 2 ) : 2 );
+	}
+	MVRT_DI bool load( uint64_t r, f3* ro, f3* rd ) const
+	{
+		uint64_t i;
+		int kind = kindOf( r, &i );
+		*ro = mk3( in->rox[i], in->roy[i], in->roz[i] );
+		if( kind == 0 ) *rd = mk3( in->rdx[i], in->rdy[i], in->rdz[i] );
+		else if( kind == 1 ) *rd = mk3( buf.sx[i], buf.sy[i], buf.sz[i] );
+		else *rd = mk3( buf.ex[i], buf.ey[i], buf.ez[i] );
+		return kind == 1;
+	}
+	MVRT_DI void store( uint64_t r, const StreamHit& h, bool )
+	{
+		uint64_t i;
+		int kind = kindOf( r, &i );
+		if( kind == 0 )
+		{
+			buf.hitT[i] = h.t;
+			buf.hitV[i] = h.vIndex;
+			buf.hitN[i] = (uint8_t)h.nMajor;
+		}
+		else if( kind == 1 )
+		{
+			buf.hitS[i] = h.t != MVRT_MAXF ? 1 : 0;
+		}
+		else
+		{
+			buf.hitE[i] = h.t != MVRT_MAXF ? 1 : 0;
+			buf.hitEV[i] = h.vIndex;
+		}
+		if( kind == 1 ) dShadow += h.descents;
+		else
+		{
+			dNormal += h.descents;
+			nHits += h.t != MVRT_MAXF ? 1 : 0;
+		}
+	}
+};
+__global__ void __launch_bounds__( 64 ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
+{
+	__shared__ uint4 ring[MVRT_RING * 64];
+	PtIO io;
+	io.buf = P.buf;
+	io.in = &P.buf.set[setIdx];
+	io.n = P.buf.liveCount[stage];
+	io.shadowKind = shadowKind;
+	io.dNormal = io.dShadow = io.nHits = 0;
+	const uint64_t total = io.n * nKinds;
+	// chunk was sized for the upper bound; shrink it when few paths are alive so every wave gets work
+	uint64_t c = total / ( (uint64_t)gridDim.x * 4 );
+	c = ( c + 63 ) / 64 * 64;
+	if( c < 64 ) c = 64;
+	if( c > chunk ) c = chunk;
+	traceStream( P.svo, io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	unsigned long long dN = waveSum( io.dNormal ), dS = waveSum( io.dShadow ), nH = waveSum( io.nHits );
+	if( threadIdx.x == 0 )
+	{
+		if( dN ) atomicAdd( &P.buf.stats[2], dN );
+		if( dS ) atomicAdd( &P.buf.stats[3], dS );
+		if( nH ) atomicAdd( &P.buf.stats[4], nH );
 	}
 }
 
@@ -639,8 +855,8 @@ __global__ void __launch_bounds__( 256 ) kPtAccumulate( PtParams P, float4* __re
 	}
 }
 
-int launchPtStep( const SvoDev& svo, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
-				  int nCUs, PtProfiler* prof, hipStream_t stream )
+int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame,
+				  const PtBuffers& buf, float4* frameBuffer, int nCUs, PtProfiler* prof, hipStream_t stream )
 {
 	PtParams P;
 	P.svo = svo;
@@ -679,7 +895,15 @@ int launchPtStep( const SvoDev& svo, const HdriDev& hdri, const float2* pmj, con
 		// upper bound for the grid: every stage has at most nSamples live paths
 		const int traceGrid = persistentGrid( nSamples * nKinds, TRACE_BLOCK, nCUs, 32 );
 		PROF_BEGIN( MVRT_K_TRACE );
-		hipLaunchKernelGGL( kPtTrace, dim3( traceGrid ), dim3( TRACE_BLOCK ), lds, stream, P, stage, setIdx, nKinds, shadowKind, extraKind );
+		if( svo.embedded && ws.spill )
+		{
+			const int g = streamGrid( nSamples * nKinds, nCUs );
+			hipLaunchKernelGGL( kPtTraceStream, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
+		}
+		else
+		{
+			hipLaunchKernelGGL( kPtTrace, dim3( traceGrid ), dim3( TRACE_BLOCK ), lds, stream, P, stage, setIdx, nKinds, shadowKind, extraKind );
+		}
 		PROF_END();
 		PROF_BEGIN( MVRT_K_OTHER );
 		hipLaunchKernelGGL( kPtAccountRays, dim3( 1 ), dim3( 1 ), 0, stream, P, stage, nKinds, shadowKind );

@@ -27,6 +27,7 @@ struct PtBuffers
 	float *Lsx, *Lsy, *Lsz; // final radiance per sample, indexed by task (read by accumulate)
 	uint32_t* blockCount; // survivors per 256-path virtual block; exclusive-scanned in place
 	uint32_t* liveCount;  // [stage] number of live paths entering stage k (0..9)
+	unsigned long long* cursors; // [16] per-stage ray cursors of the persistent traversal waves (zeroed by generate)
 	unsigned long long* stats; // [0] rays [1] shadowRays [2] descents [3] shadowDescents [4] hits [5] samples
 	uint64_t cap;
 };
@@ -40,6 +41,16 @@ struct PtFrame
 	int iteration;
 };
 
+// scratch of the persistent traversal kernels (traverse_stream.h): HBM spill rows [level][lane] + a ray cursor.
+// One workspace serves one in-flight launch: calls that share it must be ordered on one stream.
+struct TraceWorkspace
+{
+	uint4* spill;
+	uint64_t spillStride; // lanes = CUs * 32 waves * 64
+	unsigned long long* cursor;
+};
+uint64_t traceWorkspaceLanes();
+
 enum MvrtKernelClass
 {
 	MVRT_K_TRACE = 0,
@@ -47,9 +58,9 @@ enum MvrtKernelClass
 	MVRT_K_OTHER = 2
 };
 
-int launchTraceBatch( const SvoDev& svo, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy, const float* rdz,
+int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy, const float* rdz,
 					  const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream );
-int launchRenderPrimary( const SvoDev& svo, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t, int32_t* nMajor, uint32_t* vIndex,
+int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t, int32_t* nMajor, uint32_t* vIndex,
 						 uint32_t* descents, hipStream_t stream );
 int launchCompactIndices( const uint8_t* keep, uint64_t n, uint32_t* dstIndex, uint32_t* kept, uint32_t* blockScratch, hipStream_t stream );
 
@@ -59,7 +70,7 @@ struct PtProfiler
 	virtual void begin( int kernelClass, hipStream_t s ) = 0;
 	virtual void end( hipStream_t s ) = 0;
 };
-int launchPtStep( const SvoDev& svo, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
+int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
 				  int numCUs, PtProfiler* prof, hipStream_t stream );
 
 int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream );
