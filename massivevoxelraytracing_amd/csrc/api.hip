@@ -136,7 +136,8 @@ struct mvrt_svo
 	uint2* attrs = nullptr;
 	uint64_t* morton = nullptr; // only after build()
 	mutable DevBuf wsBuf;		// traversal workspace (spill rows + cursor), sized on demand
-	mutable TraceWorkspace ws = { nullptr, 0, nullptr };
+	mutable DevBuf pathBuf;
+	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0 };
 	mvrt_svo_info info;
 	uint8_t rootMask = 0;
 	mvrt_svo()
@@ -158,8 +159,14 @@ struct mvrt_svo
 		memset( &info, 0, sizeof( info ) );
 		info.emissionScale = es;
 	}
-	int ensureWorkspace() const // one per handle; users of one handle must be stream-ordered
+	int ensureWorkspace( uint64_t nPaths = 0 ) const // one per handle; users of one handle must be stream-ordered
 	{
+		if( nPaths > ws.pathCap )
+		{
+			if( pathBuf.alloc( nPaths * 12 ) ) return 1; // 8-byte path + 4-byte t scratch per ray
+			ws.paths = pathBuf.as<uint64_t>();
+			ws.pathCap = nPaths;
+		}
 		const uint64_t lanes = traceWorkspaceLanes();
 		const uint64_t levels = info.levels ? info.levels : 1;
 		const uint64_t bytes = 256 + levels * lanes * sizeof( uint4 );
@@ -318,7 +325,7 @@ MVRT_EXPORT int mvrt_trace_batch( const mvrt_svo* svo, uint64_t n, const float* 
 {
 	REQUIRE( svo && svo->nodes, "mvrt_trace_batch: no octree (build or upload first)" );
 	REQUIRE( tDev, "mvrt_trace_batch: t output is required" );
-	if( svo->ensureWorkspace() ) return 1;
+	if( svo->ensureWorkspace( vIndexDev ? n : 0 ) ) return 1;
 	return launchTraceBatch( svo->dev(), svo->ws, n, roxDev, royDev, rozDev, rdxDev, rdyDev, rdzDev, isShadowDev, tDev, nMajorDev, vIndexDev, descentsDev, (hipStream_t)stream );
 }
 
@@ -343,7 +350,7 @@ MVRT_EXPORT int mvrt_trace_batch_host( const mvrt_svo* svo, uint64_t n, const fl
 		MVRT_HIP( hipMemcpy( sh.p, isShadowHost, n, hipMemcpyHostToDevice ) );
 	}
 	const float* b = in.as<float>();
-	if( svo->ensureWorkspace() ) return 1;
+	if( svo->ensureWorkspace( n ) ) return 1;
 	if( launchTraceBatch( svo->dev(), svo->ws, n, b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, isShadowHost ? sh.as<uint8_t>() : nullptr, t.as<float>(), nm.as<int32_t>(),
 						  vi.as<uint32_t>(), de.as<uint32_t>(), 0 ) )
 		return 1;
@@ -367,7 +374,8 @@ MVRT_EXPORT int mvrt_render_primary( const mvrt_svo* svo, const float camera[15]
 {
 	REQUIRE( svo && svo->nodes, "mvrt_render_primary: no octree" );
 	REQUIRE( width > 0 && height > 0, "bad resolution %dx%d", width, height );
-	if( svo->ensureWorkspace() ) return 1;
+	if( svo->ensureWorkspace( ( vIndexDev || showVertexColor ) ? (uint64_t)width * height : 0 ) ) return 1;
+	if( !tDev && ( vIndexDev || showVertexColor ) ) tDev = (float*)( svo->ws.paths + svo->ws.pathCap ); // the resolve pass needs t
 	return launchRenderPrimary( svo->dev(), svo->ws, cameraFrom15( camera ), width, height, showVertexColor, (uchar4*)rgbaDev, tDev, nMajorDev, vIndexDev, descentsDev,
 								(hipStream_t)stream );
 }
@@ -678,7 +686,7 @@ static int allocWork( mvrt_pt* pt )
 	const uint64_t nBlocks = cap / 256 + 2;
 	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays, 4 bytes each;
 	// 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
-	const uint64_t words = cap * ( 32 + 6 + 3 + 3 );
+	const uint64_t words = cap * ( 32 + 6 + 3 + 3 + 4 );
 	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 64 * 256;
 	if( pt->work.alloc( bytes ) ) return 1;
 	uint8_t* base = (uint8_t*)pt->work.p;
@@ -698,6 +706,8 @@ static int allocWork( mvrt_pt* pt )
 	}
 	float** d[] = { &b.sx, &b.sy, &b.sz, &b.ex, &b.ey, &b.ez, &b.hitT, &b.Lsx, &b.Lsy, &b.Lsz };
 	for( float** q : d ) *q = (float*)take( cap * 4 );
+	b.hitPath = (uint64_t*)take( cap * 8 );
+	b.hitEPath = (uint64_t*)take( cap * 8 );
 	b.hitV = (uint32_t*)take( cap * 4 );
 	b.hitEV = (uint32_t*)take( cap * 4 );
 	b.hitN = (uint8_t*)take( cap );

@@ -33,7 +33,7 @@ struct BatchIO
 	const uint8_t* isShadow;
 	float* tOut;
 	int32_t* nMajorOut;
-	uint32_t* vIndexOut;
+	uint64_t* pathOut; // scratch: resolved to vIndex by kResolveVIndex
 	uint32_t* descentsOut;
 	MVRT_DI bool load( uint64_t i, f3* ro, f3* rd ) const
 	{
@@ -45,10 +45,27 @@ struct BatchIO
 	{
 		tOut[i] = h.t;
 		if( nMajorOut ) nMajorOut[i] = h.nMajor;
-		if( vIndexOut ) vIndexOut[i] = h.vIndex;
+		if( pathOut ) pathOut[i] = h.path;
 		if( descentsOut ) descentsOut[i] = h.descents;
 	}
 };
+// dense post-pass: vIndex (and optionally the primary-cast colour) from the recorded voxel paths
+__global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n, const float* __restrict__ t, const uint64_t* __restrict__ path, const uint8_t* __restrict__ isShadow,
+														  uint32_t* __restrict__ vIndexOut, uchar4* __restrict__ colorOut )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256 )
+	{
+		uint32_t v = 0;
+		const bool hit = t[i] != MVRT_MAXF;
+		if( hit && !( isShadow && isShadow[i] ) ) v = voxelIndexFromPath( svo, path[i] );
+		if( vIndexOut ) vIndexOut[i] = v;
+		if( colorOut && hit )
+		{
+			uint32_t col = svo.attrs[v].x; // IntersectorOctreeGPU::getVoxelColor, voxKernel.cu:466
+			colorOut[i] = make_uchar4( col & 0xFF, ( col >> 8 ) & 0xFF, ( col >> 16 ) & 0xFF, ( col >> 24 ) & 0xFF );
+		}
+	}
+}
 __global__ void __launch_bounds__( 64 ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
@@ -63,7 +80,7 @@ struct PrimaryIO
 	uchar4* rgba;
 	float* tOut;
 	int32_t* nMajorOut;
-	uint32_t* vIndexOut;
+	uint64_t* pathOut;
 	uint32_t* descentsOut;
 	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
 	MVRT_DI bool load( uint64_t pixelIdx, f3* ro, f3* rd )
@@ -79,12 +96,7 @@ struct PrimaryIO
 		uchar4 c = make_uchar4( 0, 0, 0, 255 );
 		if( r.t != MVRT_MAXF ) // voxKernel.cu:462-478
 		{
-			if( showVertexColor )
-			{
-				uint32_t col = svo.attrs[r.vIndex].x;
-				c = make_uchar4( col & 0xFF, ( col >> 8 ) & 0xFF, ( col >> 16 ) & 0xFF, ( col >> 24 ) & 0xFF );
-			}
-			else
+			if( !showVertexColor ) // the vertex-colour case is filled in by kResolveVIndex
 			{
 				f3 hn = getHitN( r.nMajor, rdKeep );
 				f3 color = ( hn + mk3( 1.0f, 1.0f, 1.0f ) ) * 0.5f;
@@ -94,7 +106,7 @@ struct PrimaryIO
 		if( rgba ) rgba[pixelIdx] = c;
 		if( tOut ) tOut[pixelIdx] = r.t;
 		if( nMajorOut ) nMajorOut[pixelIdx] = r.nMajor;
-		if( vIndexOut ) vIndexOut[pixelIdx] = r.vIndex;
+		if( pathOut ) pathOut[pixelIdx] = r.path;
 		if( descentsOut ) descentsOut[pixelIdx] = r.descents;
 	}
 };
@@ -198,10 +210,18 @@ int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, c
 	if( n == 0 ) return 0;
 	if( svo.embedded && ws.spill )
 	{
-		BatchIO io = { rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, vIndex, descents };
+		uint64_t* paths = vIndex ? ws.paths : nullptr;
+		if( vIndex && ws.pathCap < n )
+		{
+			mvrtSetError( "internal: path scratch too small" );
+			return 1;
+		}
+		BatchIO io = { rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, paths, descents };
 		int grid = streamGrid( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
 		hipLaunchKernelGGL( kTraceBatchStream, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		if( vIndex )
+			hipLaunchKernelGGL( kResolveVIndex, dim3( persistentGrid( n, 256, numCUs(), 8 ) ), dim3( 256 ), 0, stream, svo, n, t, paths, isShadow, vIndex, (uchar4*)nullptr );
 		MVRT_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -273,12 +293,21 @@ int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const Came
 		io.rgba = rgba;
 		io.tOut = t;
 		io.nMajorOut = nMajor;
-		io.vIndexOut = vIndex;
+		const bool needPaths = vIndex || ( showVertexColor && rgba );
+		if( needPaths && ( ws.pathCap < n || !t ) )
+		{
+			mvrtSetError( "internal: path scratch too small" );
+			return 1;
+		}
+		io.pathOut = needPaths ? ws.paths : nullptr;
 		io.descentsOut = descents;
 		io.rdKeep = mk3( 0, 0, 0 );
 		int grid = streamGrid( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
 		hipLaunchKernelGGL( kRenderPrimaryStream, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		if( needPaths )
+			hipLaunchKernelGGL( kResolveVIndex, dim3( persistentGrid( n, 256, numCUs(), 8 ) ), dim3( 256 ), 0, stream, svo, n, t, ws.paths, (const uint8_t*)nullptr, vIndex,
+								showVertexColor ? rgba : (uchar4*)nullptr );
 		MVRT_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -401,6 +430,7 @@ struct PtParams
 	PtBuffers buf;
 	int hdriEnabled;  // hdri.isEnabled(), renderCommon.hpp:467-470
 	int extraSamples; // nSampleExtraDirect = hasEmission ? 1 : 0, voxKernel.cu:721
+	int usePaths;	  // hits carry voxel paths (persistent traversal) instead of vIndex (plain traversal)
 };
 
 // owned (local) pixel -> global pixel index.  Blocks of 256 pixels dealt round-robin over tiles.
@@ -535,7 +565,7 @@ struct PtIO
 		if( kind == 0 )
 		{
 			buf.hitT[i] = h.t;
-			buf.hitV[i] = h.vIndex;
+			buf.hitPath[i] = h.path;
 			buf.hitN[i] = (uint8_t)h.nMajor;
 		}
 		else if( kind == 1 )
@@ -545,7 +575,7 @@ struct PtIO
 		else
 		{
 			buf.hitE[i] = h.t != MVRT_MAXF ? 1 : 0;
-			buf.hitEV[i] = h.vIndex;
+			buf.hitEPath[i] = h.path;
 		}
 		if( kind == 1 ) dShadow += h.descents;
 		else
@@ -724,9 +754,10 @@ __global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int
 			ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
 			rd = mk3( in.rdx[i], in.rdy[i], in.rdz[i] );
 			t = P.buf.hitT[i];
-			vIndex = P.buf.hitV[i];
 			nMajor = P.buf.hitN[i];
 			const bool hit = t != MVRT_MAXF;
+			// the persistent traversal reports the hit voxel's path; its index is summed here, all lanes together
+			vIndex = P.usePaths ? ( hit ? voxelIndexFromPath( P.svo, P.buf.hitPath[i] ) : 0u ) : P.buf.hitV[i];
 			if( stage == 0 )
 			{
 				T = mk3( 1.0f, 1.0f, 1.0f );
@@ -752,7 +783,8 @@ __global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int
 				{
 					if( P.buf.hitE[i] )
 					{
-						f3 Le = voxelEmission( P.svo, P.buf.hitEV[i], true );
+						const uint32_t ev = P.usePaths ? voxelIndexFromPath( P.svo, P.buf.hitEPath[i] ) : P.buf.hitEV[i];
+						f3 Le = voxelEmission( P.svo, ev, true );
 						L = L + T * Le / (float)( 1 + P.extraSamples );
 					}
 				}
@@ -867,6 +899,7 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 	P.buf = buf;
 	P.hdriEnabled = ( 0.0f < hdri.scale ) ? 1 : 0;
 	P.extraSamples = svo.hasEmission ? 1 : 0;
+	P.usePaths = ( svo.embedded && ws.spill ) ? 1 : 0;
 	if( nCUs <= 0 ) nCUs = numCUs();
 
 	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP;

@@ -24,6 +24,8 @@ struct PtBuffers
 	uint8_t* hitS;	  // kind 1: 1 if the shadow ray is occluded
 	uint8_t* hitE;	  // kind 2: 1 if the extra ray hit
 	uint32_t* hitEV;  // kind 2: vIndex
+	uint64_t* hitPath;	// kind 0: voxel path (persistent traversal; vIndex is derived by the shade kernel)
+	uint64_t* hitEPath; // kind 2: voxel path
 	float *Lsx, *Lsy, *Lsz; // final radiance per sample, indexed by task (read by accumulate)
 	uint32_t* blockCount; // survivors per 256-path virtual block; exclusive-scanned in place
 	uint32_t* liveCount;  // [stage] number of live paths entering stage k (0..9)
@@ -48,6 +50,8 @@ struct TraceWorkspace
 	uint4* spill;
 	uint64_t spillStride; // lanes = CUs * 32 waves * 64
 	unsigned long long* cursor;
+	uint64_t* paths; // per-ray voxel paths of batch / primary-cast launches, resolved to vIndex by a dense pass
+	uint64_t pathCap;
 };
 uint64_t traceWorkspaceLanes();
 

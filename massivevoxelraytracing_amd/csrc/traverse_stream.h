@@ -15,8 +15,9 @@
 //        min(x1,y1,z1) >= 0, so its exit times are never negative (a -0.0 would come back as +0.0,
 //        which no comparison or output can distinguish).
 //      - nVoxelSkipped is not saved at all: the path of child indices (3 bits per level, one 64-bit
-//        register) is kept instead and vIndex is summed by re-walking root -> hit voxel once, only for
-//        non-shadow rays that hit.  This also removes the nVoxelsPSum load from every descent.
+//        register = the hit voxel's morton code) is kept instead; the traversal reports that path and
+//        the CONSUMER of the hit sums nVoxelsPSum along it (voxelIndexFromPath) in a dense kernel where
+//        all 64 lanes walk together.  This also removes the nVoxelsPSum load from every descent.
 //    An entry is {child reference (index | mask << 24), tx1, ty1, tz1} = one ds_write_b128.
 //  * 4-slot LDS ring per lane (slot = level & 3) = 4 KiB per wave, so 32 waves fit a CU's 160 KiB.
 //    A push that lands on an occupied slot first evicts that (shallower) entry to an HBM spill array
@@ -36,9 +37,24 @@ struct StreamHit
 {
 	float t;
 	int nMajor;
-	uint32_t vIndex;
+	uint64_t path; // child indices root -> hit voxel, 3 bits per level (= the voxel's morton code); 0 on a miss
 	uint32_t descents;
 };
+
+// vIndex of the voxel at `path` = sum of nVoxelsPSum along root -> voxel (voxCommon.hpp:388-391).  Done by the
+// CONSUMER of a hit (dense kernels, every lane busy), not inside the divergent traversal loop.
+MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
+{
+	uint32_t n = s.rootIndex, v = 0;
+	for( uint32_t l = 0; l < s.levels; l++ )
+	{
+		const uint32_t c = (uint32_t)( path >> ( 3u * ( s.levels - 1u - l ) ) ) & 7u;
+		const Node64* nd = s.nodes + n;
+		v += nd->psum[c];
+		n = nd->children[c] & 0xFFFFFFu;
+	}
+	return v;
+}
 
 // IO concept:
 //   bool load( uint64_t ray, f3* ro, f3* rd )   -> returns isShadowRay
@@ -131,7 +147,7 @@ MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long
 							StreamHit h;
 							h.t = MVRT_MAXF;
 							h.nMajor = -1;
-							h.vIndex = 0;
+							h.path = 0;
 							h.descents = 0;
 							io.store( ray, h, isShadow );
 						}
@@ -177,21 +193,8 @@ MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long
 					StreamHit h;
 					h.t = S;
 					h.nMajor = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
-					h.vIndex = 0;
+					h.path = path; // all voxels sit at depth s.levels, so level == s.levels here
 					h.descents = descents;
-					if( !isShadow )
-					{
-						// vIndex = sum of nVoxelsPSum along root -> voxel (voxCommon.hpp:388-391), re-walked once
-						uint32_t n = s.rootIndex, v = 0;
-						for( uint32_t l = 0; l < level; l++ )
-						{
-							const uint32_t c = (uint32_t)( path >> ( 3u * ( level - 1u - l ) ) ) & 7u;
-							const Node64* nd = nodes + n;
-							v += nd->psum[c];
-							n = nd->children[c] & 0xFFFFFFu;
-						}
-						h.vIndex = v;
-					}
 					io.store( ray, h, isShadow );
 					active = false;
 				}
@@ -264,7 +267,7 @@ MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long
 					StreamHit h;
 					h.t = MVRT_MAXF;
 					h.nMajor = -1;
-					h.vIndex = 0;
+					h.path = 0;
 					h.descents = descents;
 					io.store( ray, h, isShadow );
 					active = false;
