@@ -168,8 +168,8 @@ struct mvrt_svo
 			ws.pathCap = nPaths;
 		}
 		const uint64_t lanes = traceWorkspaceLanes();
-		const uint64_t levels = info.levels ? info.levels : 1;
-		const uint64_t bytes = 256 + levels * lanes * sizeof( uint4 );
+		const uint64_t rows = 2 * (uint64_t)( info.levels ? info.levels : 1 ) + 2; // fast path: 1 row per level; irregular rays: 2 per slot
+		const uint64_t bytes = 256 + rows * lanes * sizeof( uint4 );
 		if( wsBuf.bytes < bytes )
 		{
 			if( wsBuf.alloc( bytes ) ) return 1;

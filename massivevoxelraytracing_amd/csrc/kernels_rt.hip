@@ -35,13 +35,13 @@ struct BatchIO
 	int32_t* nMajorOut;
 	uint64_t* pathOut; // scratch: resolved to vIndex by kResolveVIndex
 	uint32_t* descentsOut;
-	MVRT_DI bool load( uint64_t i, f3* ro, f3* rd ) const
+	MVRT_DI bool load( uint32_t i, f3* ro, f3* rd ) const
 	{
 		*ro = mk3( rox[i], roy[i], roz[i] );
 		*rd = mk3( rdx[i], rdy[i], rdz[i] );
 		return isShadow ? isShadow[i] != 0 : false;
 	}
-	MVRT_DI void store( uint64_t i, const StreamHit& h, bool ) const
+	MVRT_DI void store( uint32_t i, const StreamHit& h, bool ) const
 	{
 		tOut[i] = h.t;
 		if( nMajorOut ) nMajorOut[i] = h.nMajor;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 __global__ void __launch_bounds__( 64 ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	traceStream( svo, io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	traceStream( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
 }
 
 struct PrimaryIO
@@ -83,7 +83,7 @@ struct PrimaryIO
 	uint64_t* pathOut;
 	uint32_t* descentsOut;
 	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
-	MVRT_DI bool load( uint64_t pixelIdx, f3* ro, f3* rd )
+	MVRT_DI bool load( uint32_t pixelIdx, f3* ro, f3* rd )
 	{
 		int x = (int)( pixelIdx % W );
 		int y = (int)( pixelIdx / W );
@@ -91,7 +91,7 @@ struct PrimaryIO
 		rdKeep = *rd;
 		return false;
 	}
-	MVRT_DI void store( uint64_t pixelIdx, const StreamHit& r, bool ) const
+	MVRT_DI void store( uint32_t pixelIdx, const StreamHit& r, bool ) const
 	{
 		uchar4 c = make_uchar4( 0, 0, 0, 255 );
 		if( r.t != MVRT_MAXF ) // voxKernel.cu:462-478
@@ -113,7 +113,7 @@ struct PrimaryIO
 __global__ void __launch_bounds__( 64 ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	traceStream( io.svo, io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	traceStream( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
 }
 
 static uint32_t streamChunk( uint64_t total, uint64_t waves )
@@ -539,29 +539,30 @@ struct PtIO
 {
 	PtBuffers buf;
 	const PathSet* in;
-	uint64_t n;
+	uint32_t n;
 	int shadowKind;
-	unsigned long long dNormal, dShadow, nHits;
-	MVRT_DI int kindOf( uint64_t r, uint64_t* i ) const
+	uint32_t dNormal, dShadow, nHits; // per-lane tallies (a lane sees far fewer than 2^32 descents per launch)
+	MVRT_DI int kindOf( uint32_t r, uint32_t* i ) const
 	{
-		int kindSlot = ( r >= n ) + ( r >= 2 * n );
-		*i = r - (uint64_t)kindSlot * n;
+		const uint32_t kindSlot = ( r >= n ? 1u : 0u ) + ( r >= 2u * n ? 1u : 0u );
+		*i = r - kindSlot * n;
 		return kindSlot == 0 ? 0 : ( kindSlot == 1 ? ( shadowKind ? 1 : 2 ) : 2 );
 	}
-	MVRT_DI bool load( uint64_t r, f3* ro, f3* rd ) const
+	MVRT_DI bool load( uint32_t r, f3* ro, f3* rd ) const
 	{
-		uint64_t i;
-		int kind = kindOf( r, &i );
+		uint32_t i;
+		const int kind = kindOf( r, &i );
 		*ro = mk3( in->rox[i], in->roy[i], in->roz[i] );
 		if( kind == 0 ) *rd = mk3( in->rdx[i], in->rdy[i], in->rdz[i] );
 		else if( kind == 1 ) *rd = mk3( buf.sx[i], buf.sy[i], buf.sz[i] );
 		else *rd = mk3( buf.ex[i], buf.ey[i], buf.ez[i] );
 		return kind == 1;
 	}
-	MVRT_DI void store( uint64_t r, const StreamHit& h, bool )
+	MVRT_DI void store( uint32_t r, const StreamHit& h, bool )
 	{
-		uint64_t i;
-		int kind = kindOf( r, &i );
+		uint32_t i;
+		const int kind = kindOf( r, &i );
+		const bool isHit = h.t != MVRT_MAXF;
 		if( kind == 0 )
 		{
 			buf.hitT[i] = h.t;
@@ -570,19 +571,16 @@ struct PtIO
 		}
 		else if( kind == 1 )
 		{
-			buf.hitS[i] = h.t != MVRT_MAXF ? 1 : 0;
+			buf.hitS[i] = isHit ? 1 : 0;
 		}
 		else
 		{
-			buf.hitE[i] = h.t != MVRT_MAXF ? 1 : 0;
+			buf.hitE[i] = isHit ? 1 : 0;
 			buf.hitEPath[i] = h.path;
 		}
-		if( kind == 1 ) dShadow += h.descents;
-		else
-		{
-			dNormal += h.descents;
-			nHits += h.t != MVRT_MAXF ? 1 : 0;
-		}
+		dShadow += kind == 1 ? h.descents : 0u;
+		dNormal += kind == 1 ? 0u : h.descents;
+		nHits += ( kind != 1 && isHit ) ? 1u : 0u;
 	}
 };
 __global__ void __launch_bounds__( 64 ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
@@ -594,14 +592,14 @@ __global__ void __launch_bounds__( 64 ) kPtTraceStream( PtParams P, TraceWorkspa
 	io.n = P.buf.liveCount[stage];
 	io.shadowKind = shadowKind;
 	io.dNormal = io.dShadow = io.nHits = 0;
-	const uint64_t total = io.n * nKinds;
+	const uint64_t total = (uint64_t)io.n * nKinds;
 	// chunk was sized for the upper bound; shrink it when few paths are alive so every wave gets work
 	uint64_t c = total / ( (uint64_t)gridDim.x * 4 );
 	c = ( c + 63 ) / 64 * 64;
 	if( c < 64 ) c = 64;
 	if( c > chunk ) c = chunk;
-	traceStream( P.svo, io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
-	unsigned long long dN = waveSum( io.dNormal ), dS = waveSum( io.dShadow ), nH = waveSum( io.nHits );
+	traceStream( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	unsigned long long dN = waveSum( (unsigned long long)io.dNormal ), dS = waveSum( (unsigned long long)io.dShadow ), nH = waveSum( (unsigned long long)io.nHits );
 	if( threadIdx.x == 0 )
 	{
 		if( dN ) atomicAdd( &P.buf.stats[2], dN );

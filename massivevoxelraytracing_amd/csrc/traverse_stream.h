@@ -56,40 +56,180 @@ MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 	return v;
 }
 
-// IO concept:
-//   bool load( uint64_t ray, f3* ro, f3* rd )   -> returns isShadowRay
-//   void store( uint64_t ray, const StreamHit& h, bool isShadowRay )
+// What the traversal needs from the octree: kept small on purpose -- the fat SvoDev / PtParams structs cost
+// ~100 SGPRs and made the compiler re-load the node pointer from kernarg memory inside the loop.
+struct TraceCore
+{
+	const Node64* nodes;
+	float lox, loy, loz, hix, hiy, hiz;
+	uint32_t rootRef; // rootIndex | rootMask << 24 (voxCommon.hpp:306)
+};
+MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
+{
+	TraceCore c;
+	c.nodes = s.nodes;
+	c.lox = s.lower.x; c.loy = s.lower.y; c.loz = s.lower.z;
+	c.hix = s.upper.x; c.hiy = s.upper.y; c.hiz = s.upper.z;
+	c.rootRef = s.rootIndex | ( s.rootMask << 24 );
+	return c;
+}
+
+MVRT_DI uint32_t bitMask( uint32_t v, uint32_t bit ) { return (uint32_t)__builtin_amdgcn_sbfe( (int)v, bit, 1 ); } // 0 or 0xFFFFFFFF
+MVRT_DI uint32_t bfi( uint32_t mask, uint32_t a, uint32_t b ) { return ( a & mask ) | ( b & ~mask ); }			   // v_bfi_b32
+
+
+// Exact-emulation path for IRREGULAR rays: a direction component of exactly zero makes the reference's slab
+// arithmetic overflow (dt = +inf) and later produce inf - inf = NaN, which its compare-select max/min chains
+// (vectorMath.hpp:100-108) propagate in an argument-order dependent way -- such rays typically "miss" in the
+// reference even when they geometrically hit.  Parity means reproducing that, so rays whose slab deltas are not
+// all finite never enter the fast loop (whose v_max3/v_min3 assume NaN-free data); they are traced here, one
+// lane at a time if need be, with the reference's exact operation order and a stack in the HBM spill rows
+// (two 16-byte rows per slot).  They are measure-zero in rendering; cost is irrelevant.
+MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1, float t0x, float t0y, float t0z, uint32_t vMask, uint4* __restrict__ mySpill,
+							 uint64_t spillStride, float* resT, int* resN, uint64_t* pathOut, uint32_t* descentsOut )
+{
+	const float dtx = tx1 - t0x, dty = ty1 - t0y, dtz = tz1 - t0z;
+	uint32_t node = s.rootRef, level = 0, childMask = 8u, sp = 0, descents = 0;
+	uint64_t path = 0;
+	for( ;; )
+	{
+		const float scale = mvrt_u2f( ( 127u - level ) << 23 );
+		const float tx0 = tx1 - dtx * scale;
+		const float ty0 = ty1 - dty * scale;
+		const float tz0 = tz1 - dtz * scale;
+		const float S = max3f( tx0, ty0, tz0 );
+		bool pop = false;
+		if( node == MVRT_LEAF )
+		{
+			if( 0.0f < S )
+			{
+				*resT = S;
+				*resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
+				break;
+			}
+			pop = true;
+		}
+		else
+		{
+			const float txM = 0.5f * ( tx0 + tx1 );
+			const float tyM = 0.5f * ( ty0 + ty1 );
+			const float tzM = 0.5f * ( tz0 + tz1 );
+			if( childMask & 8u ) childMask = ( txM < S ? 1u : 0u ) | ( tyM < S ? 2u : 0u ) | ( tzM < S ? 4u : 0u );
+			const float x1 = ( childMask & 1u ) ? tx1 : txM;
+			const float y1 = ( childMask & 2u ) ? ty1 : tyM;
+			const float z1 = ( childMask & 4u ) ? tz1 : tzM;
+			const float u = min3f( x1, y1, z1 );
+			const uint32_t mv = ( u == x1 ) ? 1u : ( ( u == y1 ) ? 2u : 4u );
+			const bool hasNext = ( childMask & mv ) == 0;
+			const uint32_t childIndex = childMask ^ vMask;
+			const uint32_t nextMask = childMask | mv;
+			if( ( ( node >> ( 24u + childIndex ) ) & 1u ) && !( u < 0.0f ) )
+			{
+				if( hasNext )
+				{
+					uint4 a, b;
+					a.x = node;
+					a.y = mvrt_f2u( tx1 );
+					a.z = mvrt_f2u( ty1 );
+					a.w = mvrt_f2u( tz1 );
+					b.x = nextMask | ( level << 3 );
+					b.y = (uint32_t)path;
+					b.z = (uint32_t)( path >> 32 );
+					b.w = 0;
+					mySpill[(uint64_t)( 2 * sp ) * spillStride] = a;
+					mySpill[(uint64_t)( 2 * sp + 1 ) * spillStride] = b;
+					sp++;
+				}
+				node = s.nodes[node & 0xFFFFFFu].children[childIndex];
+				descents++;
+				path = ( path << 3 ) | childIndex;
+				tx1 = x1;
+				ty1 = y1;
+				tz1 = z1;
+				level++;
+				childMask = 8u;
+			}
+			else if( hasNext )
+			{
+				childMask = nextMask;
+			}
+			else
+			{
+				pop = true;
+			}
+		}
+		if( pop )
+		{
+			if( sp == 0 ) break;
+			sp--;
+			const uint4 a = mySpill[(uint64_t)( 2 * sp ) * spillStride];
+			const uint4 b = mySpill[(uint64_t)( 2 * sp + 1 ) * spillStride];
+			node = a.x;
+			tx1 = mvrt_u2f( a.y );
+			ty1 = mvrt_u2f( a.z );
+			tz1 = mvrt_u2f( a.w );
+			childMask = b.x & 7u;
+			level = ( b.x >> 3 ) & 31u;
+			path = (uint64_t)b.y | ( (uint64_t)b.z << 32 );
+		}
+	}
+	*pathOut = path;
+	*descentsOut = descents;
+}
+
+// IO concept (ray indices are 32-bit: a launch never exceeds 2^32 rays):
+//   bool load( uint32_t ray, f3* ro, f3* rd )   -> returns isShadowRay
+//   void store( uint32_t ray, const StreamHit& h, bool isShadowRay )
+//
+// One loop iteration = (1) refill when enough lanes are idle: first STORE the results those lanes still hold
+// (one store site, many lanes per store instruction), then load new rays into them; (2) one traversal step for
+// every active lane: straight-line bit arithmetic (v_bfi / v_bfe selects instead of compare-select chains)
+// followed by three shallow branches: descend (with push), pop, hit.
 template <class IO>
-MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING][64] */,
+MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING][64] */,
 						  uint4* __restrict__ spill /* [levels][spillStride] */, uint64_t spillStride, uint64_t spillLane )
 {
 	const uint32_t lane = threadIdx.x;
+	const uint32_t total = (uint32_t)total64;
 	const Node64* __restrict__ nodes = s.nodes;
+	uint4* const myRing = ldsRing + lane;	  // slot k at myRing[k * 64]
+	uint4* const mySpill = spill + spillLane; // level L at mySpill[L * spillStride]
 
 	// wave-uniform cursor state
-	uint64_t chunkNext = 0, chunkEnd = 0;
+	uint32_t chunkNext = 0, chunkEnd = 0;
 	bool exhausted = false;
 
-	// per-lane ray state
-	bool active = false;
+	// per-lane state.  st: 0 idle, 1 traversing, 2 finished and holding a result that is not stored yet
+	uint32_t st = 0;
 	bool isShadow = false;
-	uint64_t ray = 0;
+	uint32_t ray = 0;
 	float dtx = 0, dty = 0, dtz = 0, tx1 = 0, ty1 = 0, tz1 = 0;
 	uint32_t vMask = 0, node = 0, level = 0, childMask = 8u, pending = 0, inLds = 0, descents = 0;
 	uint64_t path = 0;
+	float resT = MVRT_MAXF;
+	int resN = -1;
 
 	for( ;; )
 	{
-		// ---------------- refill ----------------
-		const unsigned long long idleMask = __ballot( !active );
+		// ---------------- (1) refill ----------------
+		const unsigned long long idleMask = __ballot( st != 1u );
 		const uint32_t nIdle = __popcll( idleMask );
 		if( nIdle == 64 || ( nIdle >= MVRT_REFILL_MIN && !exhausted ) )
 		{
+			if( st == 2u ) // flush results of the lanes that finished since the last refill
+			{
+				StreamHit h;
+				h.t = resT;
+				h.nMajor = resN;
+				h.path = resT != MVRT_MAXF ? path : 0ull;
+				h.descents = descents;
+				io.store( ray, h, isShadow );
+				st = 0;
+			}
 			if( !exhausted )
 			{
-				// hand out rays [chunkNext, ...) to idle lanes in lane order; grab new chunks as needed
 				uint32_t need = nIdle;
-				uint32_t myRank = __popcll( idleMask & ( ( 1ull << lane ) - 1ull ) );
+				const uint32_t myRank = __popcll( idleMask & ( ( 1ull << lane ) - 1ull ) );
 				uint32_t given = 0;
 				while( need > 0 )
 				{
@@ -103,12 +243,12 @@ MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long
 							exhausted = true;
 							break;
 						}
-						chunkNext = base;
-						chunkEnd = base + chunk < total ? base + chunk : total;
+						chunkNext = (uint32_t)base;
+						chunkEnd = ( total - chunkNext ) < chunk ? total : chunkNext + chunk;
 					}
-					uint32_t avail = (uint32_t)( chunkEnd - chunkNext );
-					uint32_t take = avail < need ? avail : need;
-					if( !active && myRank >= given && myRank < given + take )
+					const uint32_t avail = chunkEnd - chunkNext;
+					const uint32_t take = avail < need ? avail : need;
+					if( st == 0u && myRank >= given && myRank < given + take )
 					{
 						ray = chunkNext + ( myRank - given );
 						// ---- ray setup, voxCommon.hpp:240-312 ----
@@ -120,49 +260,53 @@ MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long
 						{
 							vMask |= 1u;
 							ix = -ix;
-							ro.x = s.lower.x + s.upper.x - ro.x;
+							ro.x = s.lox + s.hix - ro.x;
 						}
 						if( iy < 0.0f )
 						{
 							vMask |= 2u;
 							iy = -iy;
-							ro.y = s.lower.y + s.upper.y - ro.y;
+							ro.y = s.loy + s.hiy - ro.y;
 						}
 						if( iz < 0.0f )
 						{
 							vMask |= 4u;
 							iz = -iz;
-							ro.z = s.lower.z + s.upper.z - ro.z;
+							ro.z = s.loz + s.hiz - ro.z;
 						}
-						ix = smin( ix, MVRT_MAXF / smax( smax( sabs( s.lower.x - ro.x ), sabs( s.upper.x - ro.x ) ), 1.0f ) );
-						iy = smin( iy, MVRT_MAXF / smax( smax( sabs( s.lower.y - ro.y ), sabs( s.upper.y - ro.y ) ), 1.0f ) );
-						iz = smin( iz, MVRT_MAXF / smax( smax( sabs( s.lower.z - ro.z ), sabs( s.upper.z - ro.z ) ), 1.0f ) );
-						const float t0x = ( s.lower.x - ro.x ) * ix, t0y = ( s.lower.y - ro.y ) * iy, t0z = ( s.lower.z - ro.z ) * iz;
-						tx1 = ( s.upper.x - ro.x ) * ix;
-						ty1 = ( s.upper.y - ro.y ) * iy;
-						tz1 = ( s.upper.z - ro.z ) * iz;
+						ix = smin( ix, MVRT_MAXF / smax( smax( sabs( s.lox - ro.x ), sabs( s.hix - ro.x ) ), 1.0f ) );
+						iy = smin( iy, MVRT_MAXF / smax( smax( sabs( s.loy - ro.y ), sabs( s.hiy - ro.y ) ), 1.0f ) );
+						iz = smin( iz, MVRT_MAXF / smax( smax( sabs( s.loz - ro.z ), sabs( s.hiz - ro.z ) ), 1.0f ) );
+						const float t0x = ( s.lox - ro.x ) * ix, t0y = ( s.loy - ro.y ) * iy, t0z = ( s.loz - ro.z ) * iz;
+						tx1 = ( s.hix - ro.x ) * ix;
+						ty1 = ( s.hiy - ro.y ) * iy;
+						tz1 = ( s.hiz - ro.z ) * iz;
 						descents = 0;
-						if( min3f( tx1, ty1, tz1 ) < max3f( t0x, t0y, t0z ) ) // :275-278 miss the root box
+						path = 0;
+						resT = MVRT_MAXF;
+						resN = -1;
+						if( min3f( tx1, ty1, tz1 ) < max3f( t0x, t0y, t0z ) ) // :275-278 misses the root box
 						{
-							StreamHit h;
-							h.t = MVRT_MAXF;
-							h.nMajor = -1;
-							h.path = 0;
-							h.descents = 0;
-							io.store( ray, h, isShadow );
+							st = 2u;
+						}
+						else if( ( ( mvrt_f2u( tx1 - t0x ) & 0x7F800000u ) == 0x7F800000u ) || ( ( mvrt_f2u( ty1 - t0y ) & 0x7F800000u ) == 0x7F800000u ) ||
+								 ( ( mvrt_f2u( tz1 - t0z ) & 0x7F800000u ) == 0x7F800000u ) )
+						{
+							// irregular ray (inf / NaN slab delta): exact reference emulation, see traceIrregular
+							traceIrregular( s, tx1, ty1, tz1, t0x, t0y, t0z, vMask, mySpill, spillStride, &resT, &resN, &path, &descents );
+							st = 2u;
 						}
 						else
 						{
 							dtx = tx1 - t0x;
 							dty = ty1 - t0y;
 							dtz = tz1 - t0z;
-							node = s.rootIndex | ( s.rootMask << 24 ); // :306
+							node = s.rootRef;
 							level = 0;
 							childMask = 8u;
 							pending = 0;
 							inLds = 0;
-							path = 0;
-							active = true;
+							st = 1u;
 						}
 					}
 					given += take;
@@ -170,125 +314,116 @@ MVRT_DI void traceStream( const SvoDev& s, IO& io, uint64_t total, unsigned long
 					chunkNext += take;
 				}
 			}
-			if( __ballot( active ) == 0ull )
+			if( __ballot( st == 1u ) == 0ull )
 			{
-				if( exhausted ) break; // every lane idle and the stream is empty: the wave retires
-				continue;			   // all the rays just loaded missed the root box: fetch again
+				if( !exhausted ) continue; // every ray just loaded missed the root box: go round again
+				if( st == 2u )			   // final flush
+				{
+					StreamHit h;
+					h.t = resT;
+					h.nMajor = resN;
+					h.path = resT != MVRT_MAXF ? path : 0ull;
+					h.descents = descents;
+					io.store( ray, h, isShadow );
+				}
+				break; // every lane idle and the stream is empty: the wave retires
 			}
 		}
 
-		// ---------------- one traversal step for every active lane ----------------
-		if( active )
+		// ---------------- (2) one traversal step ----------------
+		if( st == 1u )
 		{
 			const float scale = mvrt_u2f( ( 127u - level ) << 23 );
 			const float tx0 = tx1 - dtx * scale; // :317-320
 			const float ty0 = ty1 - dty * scale;
 			const float tz0 = tz1 - dtz * scale;
-			const float S = max3f( tx0, ty0, tz0 );
-			bool pop = false;
-			if( node == MVRT_LEAF ) // :322-336
+			// no NaNs can reach here (the direction clamp keeps every product finite), so max3/min3 equal the
+			// reference's compare-select chains up to the sign of a zero, which no decision below can see
+			const float S = fmaxf( fmaxf( tx0, ty0 ), tz0 );
+			const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
+			const float tyM = 0.5f * ( ty0 + ty1 );
+			const float tzM = 0.5f * ( tz0 + tz1 );
+			// first visit: childMask bit = (tM < S) = sign bit of (tM - S)  (:342-348; the difference of two
+			// distinct floats is never zero with denormals on, and x - x = +0)
+			const uint32_t cmInit = ( mvrt_f2u( txM - S ) >> 31 ) | ( ( mvrt_f2u( tyM - S ) >> 30 ) & 2u ) | ( ( mvrt_f2u( tzM - S ) >> 29 ) & 4u );
+			const uint32_t cm = bfi( bitMask( childMask, 3 ), cmInit, childMask & 7u );
+			const float x1 = mvrt_u2f( bfi( bitMask( cm, 0 ), mvrt_f2u( tx1 ), mvrt_f2u( txM ) ) ); // :358-360
+			const float y1 = mvrt_u2f( bfi( bitMask( cm, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
+			const float z1 = mvrt_u2f( bfi( bitMask( cm, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
+			const float u = fminf( fminf( x1, y1 ), z1 );					  // :365
+			const uint32_t mv = ( u == x1 ) ? 1u : ( ( u == y1 ) ? 2u : 4u ); // :366
+			const uint32_t childIndex = cm ^ vMask;							  // :369
+			const uint32_t nextMask = cm | mv;								  // :370
+			const bool leaf = node == MVRT_LEAF;							  // :322
+			const bool hasNext = ( cm & mv ) == 0;							  // :368
+			const bool exists = ( ( node >> ( 24u + childIndex ) ) & 1u ) != 0;
+			const bool go = !leaf && exists && !( u < 0.0f ); // :373-375
+			const bool hit = leaf && ( 0.0f < S );			  // :324
+			const bool pop = leaf ? !hit : ( !go && !hasNext );
+			// advance within the node (:396-411): only the child mask changes
+			childMask = leaf ? childMask : ( ( !go && hasNext ) ? nextMask : cm );
+
+			if( go )
 			{
-				if( 0.0f < S )
+				if( hasNext ) // push (:377-380)
 				{
-					StreamHit h;
-					h.t = S;
-					h.nMajor = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
-					h.path = path; // all voxels sit at depth s.levels, so level == s.levels here
-					h.descents = descents;
-					io.store( ray, h, isShadow );
-					active = false;
-				}
-				else
-				{
-					pop = true;
-				}
-			}
-			else
-			{
-				const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
-				const float tyM = 0.5f * ( ty0 + ty1 );
-				const float tzM = 0.5f * ( tz0 + tz1 );
-				if( childMask & 8u ) // :342-348
-				{
-					childMask = ( txM < S ? 1u : 0u ) | ( tyM < S ? 2u : 0u ) | ( tzM < S ? 4u : 0u );
-				}
-				const float x1 = ( childMask & 1u ) ? tx1 : txM; // :358-360
-				const float y1 = ( childMask & 2u ) ? ty1 : tyM;
-				const float z1 = ( childMask & 4u ) ? tz1 : tzM;
-				const float u = min3f( x1, y1, z1 );							  // :365
-				const uint32_t mv = ( u == x1 ) ? 1u : ( ( u == y1 ) ? 2u : 4u ); // :366
-				const bool hasNext = ( childMask & mv ) == 0;					  // :368
-				const uint32_t childIndex = childMask ^ vMask;					  // :369
-				const uint32_t nextMask = childMask | mv;						  // :370
-				const bool go = ( ( node >> ( 24u + childIndex ) ) & 1u ) && !( u < 0.0f );
-				if( go )
-				{
-					if( hasNext ) // push (:377-380)
+					const uint32_t slot = level & ( MVRT_RING - 1 );
+					const uint32_t clash = inLds & ( 0x11111111u << slot );
+					if( clash ) // the slot still holds a shallower pending entry: evict it to HBM
 					{
-						const uint32_t slot = level & ( MVRT_RING - 1 );
-						const uint32_t clash = inLds & ( 0x11111111u << slot );
-						if( clash ) // the slot still holds a shallower pending entry: evict it to HBM
-						{
-							const uint32_t lc = __builtin_ctz( clash );
-							spill[(uint64_t)lc * spillStride + spillLane] = ldsRing[slot * 64 + lane];
-							inLds &= ~clash;
-						}
-						uint4 e;
-						e.x = node;
-						e.y = ( __float_as_uint( tx1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 1u ) << 31 );
-						e.z = ( __float_as_uint( ty1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 2u ) << 30 );
-						e.w = ( __float_as_uint( tz1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 4u ) << 29 );
-						ldsRing[slot * 64 + lane] = e;
-						pending |= 1u << level;
-						inLds |= 1u << level;
+						const uint32_t lc = __builtin_ctz( clash );
+						mySpill[(uint64_t)lc * spillStride] = myRing[slot * 64];
+						inLds &= ~clash;
 					}
-					node = nodes[node & 0xFFFFFFu].children[childIndex]; // :381
-					descents++;
-					path = ( path << 3 ) | childIndex;
-					tx1 = x1; // :382-386
-					ty1 = y1;
-					tz1 = z1;
-					level++;
-					childMask = 8u;
+					uint4 e;
+					e.x = node;
+					e.y = ( mvrt_f2u( tx1 ) & 0x7FFFFFFFu ) | ( nextMask << 31 );
+					e.z = ( mvrt_f2u( ty1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 2u ) << 30 );
+					e.w = ( mvrt_f2u( tz1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 4u ) << 29 );
+					myRing[slot * 64] = e;
+					pending |= 1u << level;
+					inLds |= 1u << level;
 				}
-				else if( hasNext ) // :396-411
-				{
-					childMask = nextMask;
-				}
-				else
-				{
-					pop = true;
-				}
+				node = nodes[node & 0xFFFFFFu].children[childIndex]; // :381
+				descents++;
+				path = ( path << 3 ) | childIndex;
+				tx1 = x1; // :382-386
+				ty1 = y1;
+				tz1 = z1;
+				level++;
+				childMask = 8u;
 			}
 			if( pop ) // :414-422
 			{
-				if( pending == 0 )
+				if( pending == 0 ) // miss
 				{
-					StreamHit h;
-					h.t = MVRT_MAXF;
-					h.nMajor = -1;
-					h.path = 0;
-					h.descents = descents;
-					io.store( ray, h, isShadow );
-					active = false;
+					st = 2u;
 				}
 				else
 				{
 					const uint32_t L = 31u - __builtin_clz( pending );
 					const uint32_t bit = 1u << L;
-					uint4 e;
-					if( inLds & bit ) e = ldsRing[( L & ( MVRT_RING - 1 ) ) * 64 + lane];
-					else e = spill[(uint64_t)L * spillStride + spillLane];
+					uint4 e = myRing[( L & ( MVRT_RING - 1 ) ) * 64]; // speculative LDS read (valid iff inLds & bit)
+					if( !( inLds & bit ) )
+					{
+						e = mySpill[(uint64_t)L * spillStride];
+					}
 					pending &= ~bit;
 					inLds &= ~bit;
 					path >>= 3u * ( level - L );
 					level = L;
 					node = e.x;
-					childMask = ( e.y >> 31 ) | ( ( e.z >> 31 ) << 1 ) | ( ( e.w >> 31 ) << 2 );
-					tx1 = __uint_as_float( e.y & 0x7FFFFFFFu );
-					ty1 = __uint_as_float( e.z & 0x7FFFFFFFu );
-					tz1 = __uint_as_float( e.w & 0x7FFFFFFFu );
+					childMask = ( e.y >> 31 ) | ( ( e.z >> 30 ) & 2u ) | ( ( e.w >> 29 ) & 4u );
+					tx1 = mvrt_u2f( e.y & 0x7FFFFFFFu );
+					ty1 = mvrt_u2f( e.z & 0x7FFFFFFFu );
+					tz1 = mvrt_u2f( e.w & 0x7FFFFFFFu );
 				}
+			}
+			if( hit ) // :324-334
+			{
+				resT = S;
+				resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
+				st = 2u;
 			}
 		}
 	}
