@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvrt_hip.so")
+LIB_PATH = os.environ.get("MVRT_LIB", os.path.join(_HERE, "libmvrt_hip.so"))  # MVRT_LIB: A/B builds of the same library
 MAX_FLOAT = np.float32(3.402823466e38)
 
 _vp, _i32, _u32, _u64, _f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float

@@ -11,14 +11,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libmvrt_hip.so")
+OUT = os.environ.get("MVRT_LIB_OUT", os.path.join(HERE, "libmvrt_hip.so"))
 SOURCES = ["api.hip", "kernels_rt.hip", "kernels_setup.hip", "svo_build.hip"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
     "-fgpu-rdc" if False else "-fno-gpu-rdc",
     "-Wall", "-Wno-unused-function", "-Wno-unused-result",
-]
+] + os.environ.get("MVRT_EXTRA_FLAGS", "").split()
 
 
 def needs_build():

@@ -3,6 +3,7 @@
 // (IntersectorOctreeGPU.hpp:21-275) and PathTracer (PathTracer.hpp:14-170) behind opaque handles.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -917,6 +918,13 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 		out->shadowDescents = s[3];
 		out->hits = s[4];
 		out->samples = s[5];
+		if( getenv( "MVRT_PRINT_UTIL" ) )
+		{
+			unsigned long long u[4];
+			MVRT_HIP( hipMemcpy( u, pt->buf.stats + 8, sizeof( u ), hipMemcpyDeviceToHost ) );
+			fprintf( stderr, "[util] wave-iterations %llu active-lane-iterations %llu (%.1f%% of lane slots); after stream exhausted: %llu wave-iterations (%.1f%% of all), %.1f%% lane use\n", u[0], u[1],
+					 100.0 * u[1] / ( 64.0 * ( u[0] ? u[0] : 1 ) ), u[2], 100.0 * u[2] / ( u[0] ? u[0] : 1 ), 100.0 * u[3] / ( 64.0 * ( u[2] ? u[2] : 1 ) ) );
+		}
 	}
 	pt->prof.collect();
 	out->traceLaunches = pt->prof.traceLaunches;

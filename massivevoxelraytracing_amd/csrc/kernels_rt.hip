@@ -35,6 +35,9 @@ struct BatchIO
 	int32_t* nMajorOut;
 	uint64_t* pathOut; // scratch: resolved to vIndex by kResolveVIndex
 	uint32_t* descentsOut;
+#ifdef MVRT_UTIL_STATS
+	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+#endif
 	MVRT_DI bool load( uint32_t i, f3* ro, f3* rd ) const
 	{
 		*ro = mk3( rox[i], roy[i], roz[i] );
@@ -82,6 +85,9 @@ struct PrimaryIO
 	int32_t* nMajorOut;
 	uint64_t* pathOut;
 	uint32_t* descentsOut;
+#ifdef MVRT_UTIL_STATS
+	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+#endif
 	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
 	MVRT_DI bool load( uint32_t pixelIdx, f3* ro, f3* rd )
 	{
@@ -541,6 +547,9 @@ struct PtIO
 	const PathSet* in;
 	uint32_t n;
 	int shadowKind;
+#ifdef MVRT_UTIL_STATS
+	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+#endif
 	uint32_t dNormal, dShadow, nHits; // per-lane tallies (a lane sees far fewer than 2^32 descents per launch)
 	MVRT_DI int kindOf( uint32_t r, uint32_t* i ) const
 	{
@@ -583,7 +592,10 @@ struct PtIO
 		nHits += ( kind != 1 && isHit ) ? 1u : 0u;
 	}
 };
-__global__ void __launch_bounds__( 64 ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
+#ifndef MVRT_TRACE_WAVES
+#define MVRT_TRACE_WAVES 1
+#endif
+__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
 	PtIO io;
@@ -593,13 +605,38 @@ __global__ void __launch_bounds__( 64 ) kPtTraceStream( PtParams P, TraceWorkspa
 	io.shadowKind = shadowKind;
 	io.dNormal = io.dShadow = io.nHits = 0;
 	const uint64_t total = (uint64_t)io.n * nKinds;
+#ifdef MVRT_RAYS_PER_LANE
+	{
+		// small launches: fewer, longer-lived waves keep their lanes refilled instead of idling in a long tail
+		uint64_t wantWaves = total / ( 64ull * MVRT_RAYS_PER_LANE ) + 1;
+		if( wantWaves < MVRT_MIN_WAVES ) wantWaves = MVRT_MIN_WAVES;
+		if( blockIdx.x >= wantWaves ) return;
+	}
+#endif
 	// chunk was sized for the upper bound; shrink it when few paths are alive so every wave gets work
-	uint64_t c = total / ( (uint64_t)gridDim.x * 4 );
+	uint64_t nWaves = gridDim.x;
+#ifdef MVRT_RAYS_PER_LANE
+	{
+		uint64_t wantWaves = total / ( 64ull * MVRT_RAYS_PER_LANE ) + 1;
+		if( wantWaves < MVRT_MIN_WAVES ) wantWaves = MVRT_MIN_WAVES;
+		if( wantWaves < nWaves ) nWaves = wantWaves;
+	}
+#endif
+	uint64_t c = total / ( nWaves * 4 );
 	c = ( c + 63 ) / 64 * 64;
 	if( c < 64 ) c = 64;
 	if( c > chunk ) c = chunk;
 	traceStream( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
 	unsigned long long dN = waveSum( (unsigned long long)io.dNormal ), dS = waveSum( (unsigned long long)io.dShadow ), nH = waveSum( (unsigned long long)io.nHits );
+#ifdef MVRT_UTIL_STATS
+	if( threadIdx.x == 0 )
+	{
+		atomicAdd( &P.buf.stats[8 + 0], io.utilIters );
+		atomicAdd( &P.buf.stats[8 + 1], io.utilActive );
+		atomicAdd( &P.buf.stats[8 + 2], io.utilTailIters );
+		atomicAdd( &P.buf.stats[8 + 3], io.utilTailActive );
+	}
+#endif
 	if( threadIdx.x == 0 )
 	{
 		if( dN ) atomicAdd( &P.buf.stats[2], dN );

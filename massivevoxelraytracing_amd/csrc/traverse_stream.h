@@ -31,7 +31,9 @@
 #include "mvrt_common.h"
 
 #define MVRT_RING 4			// LDS ring slots per lane
-#define MVRT_REFILL_MIN 20	// refill once this many lanes are idle (or all of them)
+#ifndef MVRT_REFILL_MIN
+#define MVRT_REFILL_MIN 20 // refill once this many lanes are idle (or all of them)
+#endif
 
 struct StreamHit
 {
@@ -330,6 +332,18 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			}
 		}
 
+#ifdef MVRT_UTIL_STATS
+		{
+			const unsigned long long am = __ballot( st == 1u );
+			if( lane == 0 )
+			{
+				io.utilIters++;
+				io.utilActive += __popcll( am );
+				io.utilTailIters += exhausted ? 1u : 0u;
+				io.utilTailActive += exhausted ? __popcll( am ) : 0u;
+			}
+		}
+#endif
 		// ---------------- (2) one traversal step ----------------
 		if( st == 1u )
 		{
