@@ -55,10 +55,13 @@ def main():
         args.gpus = world
     dist = None
     torch = None
-    if world > 1:
+    force_dist = os.environ.get("MVRT_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch  # noqa: F811  (device memory for the collective + torch.distributed over RCCL)
         import torch.distributed as dist  # noqa: F811
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import massivevoxelraytracing_amd as mv
@@ -143,11 +146,17 @@ def main():
     launches = max(int(st["traceLaunches"]), 1)
     trace_ms = st["traceKernelMs"]
     roofline = None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if args.scene == "dragon" and args.grid_res == 2048 and (W, H) == (1920, 1080) and os.path.exists(tpath):
+        # HBM-side bytes cannot be read live: they come from the separate rocprofv3 --pmc passes of this same command
+        traffic = json.load(open(tpath))
     if trace_ms > 0:
         achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "kPtTrace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "bound": "hbm", "kernel": "kPtTraceStream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": int(traffic["traffic_bytes_per_launch"]) if traffic else None, "traffic_source": traffic["_source"] if traffic else None,
             "algorithmic_bytes_per_launch": int(algo_bytes / launches), "avg_launch_ms": round(trace_ms / launches, 4), "launches": launches,
             "bytes_per_ray": round(algo_bytes / max(st["rays"], 1), 2),
             "descents_per_ray": round((st["descents"] + st["shadowDescents"]) / max(st["rays"], 1), 2),
