@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--emulate-tiles", type=int, default=0, help="diagnostic: render only tile 0 of N on one GPU (predicts per-rank time of an N-GPU run)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
 
@@ -82,7 +83,7 @@ def main():
     W, H = args.width, args.height
     pt = mv.PathTracer()
     pt.setup(None)
-    pt.set_tile(rank, world)
+    pt.set_tile(rank, world) if not args.emulate_tiles else pt.set_tile(0, args.emulate_tiles)
     pt.resizeFrameBufferIfNeeded(None, W, H)
     hdr = os.path.join(ROOT, "tests", "golden", "monks_forest_s.hdr")
     pt.loadHDRI(None, hdr, hdr)
@@ -112,6 +113,7 @@ def main():
         for _ in range(k):
             pt.step(None, cam)
         if dist is not None:
+            pt.join(None)
             mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16)
             mv.synchronize()  # the copy ran on the null stream; RCCL uses torch's stream
             dist.all_gather_into_tensor(gather_out, gather_in)

@@ -140,6 +140,13 @@ mvrt_svo* mvrt_pt_intersector( mvrt_pt* pt ); /* &PathTracer::m_intersectorOctre
 int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] );
 /* same with the matrices GetCameraMatrix produces in the reference (:152-156) */
 int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], const float proj[16], float focus, float lensR );
+/* Consecutive step() calls are pipelined on internal streams (`depth` steps in flight, default 2; 1 = none) so that
+ * the thin late bounces of one step overlap the dense early bounces of the next.  Results are unchanged (frame-buffer
+ * additions are chained in step order).  Every call that consumes the frame buffer (resolve, to_image, read, clear)
+ * first makes `stream` wait for the steps in flight; callers that read mvrt_pt_framebuffer_dev() themselves call
+ * mvrt_pt_join( pt, stream ) before. */
+int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth );
+int mvrt_pt_join( mvrt_pt* pt, void* stream );
 int mvrt_pt_resolve( mvrt_pt* pt, void* stream );						/* :130-137, renderResolve */
 int mvrt_pt_to_image_async( mvrt_pt* pt, void* stream, uint8_t* rgbaHost ); /* :118-129 resolve + DtoH (caller syncs) */
 int mvrt_pt_get_steps( const mvrt_pt* pt );								/* :33 */

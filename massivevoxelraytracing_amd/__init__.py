@@ -75,6 +75,8 @@ SIGNATURES = {
     "mvrt_pt_intersector": (_vp, [_vp]),
     "mvrt_pt_step": (_i32, [_vp, _vp, _vp]),
     "mvrt_pt_step_matrices": (_i32, [_vp, _vp, _vp, _vp, _f32, _f32]),
+    "mvrt_pt_set_pipeline_depth": (_i32, [_vp, _i32]),
+    "mvrt_pt_join": (_i32, [_vp, _vp]),
     "mvrt_pt_resolve": (_i32, [_vp, _vp]),
     "mvrt_pt_to_image_async": (_i32, [_vp, _vp, _vp]),
     "mvrt_pt_get_steps": (_i32, [_vp]),
@@ -383,6 +385,13 @@ class PathTracer:
             if lensR is not None:
                 cam[13] = lensR
             _check(lib().mvrt_pt_step(self._h, stream, _hp(cam)))
+
+    def set_pipeline_depth(self, depth):
+        _check(lib().mvrt_pt_set_pipeline_depth(self._h, depth))
+
+    def join(self, stream=None):
+        """make `stream` wait for the steps still in flight on the internal streams"""
+        _check(lib().mvrt_pt_join(self._h, stream))
 
     def resolve(self, stream=None):
         _check(lib().mvrt_pt_resolve(self._h, stream))

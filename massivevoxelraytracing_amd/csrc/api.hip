@@ -619,9 +619,25 @@ struct mvrt_pt
 	int width = 0, height = 0, steps = 0;
 	int tileIndex = 0, tileCount = 1;
 	uint64_t ownedPixels = 0, validOwnedPixels = 0;
-	// wavefront work buffers
-	DevBuf work;
-	PtBuffers buf;
+	// wavefront work buffers: one set per in-flight step.  Consecutive step() calls are pipelined on internal
+	// streams (depth slots) so that the thin late bounces of one step overlap the dense early bounces of the next;
+	// the frame-buffer additions stay in step order through an event chain.  depth 1 = everything on the caller's stream.
+	struct Slot
+	{
+		DevBuf work, wsBuf;
+		PtBuffers buf;
+		TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0 };
+		hipStream_t stream = nullptr;
+		hipEvent_t accumDone = nullptr;
+	};
+	Slot slots[4];
+	int depth = 2;
+	int nextSlot = 0, lastSlot = 0;
+	DevBuf statsBuf;
+	hipEvent_t forkEv = nullptr;
+	hipEvent_t lastAccum = nullptr;
+	bool pendingJoin = false;
+	PtBuffers& buf = slots[0].buf; // slot 0 doubles as "the" buffer set for capacity / stats bookkeeping
 	bool setupDone = false;
 	bool profiling = false;
 	EventProfiler prof;
@@ -630,7 +646,38 @@ struct mvrt_pt
 	{
 		memset( &hdri, 0, sizeof( hdri ) );
 		hdri.scale = 1.75f; // renderCommon.hpp:480
-		memset( &buf, 0, sizeof( buf ) );
+		for( Slot& sl : slots ) memset( &sl.buf, 0, sizeof( sl.buf ) );
+		const char* e = getenv( "MVRT_PIPELINE_DEPTH" );
+		if( e ) depth = atoi( e );
+		if( depth < 1 ) depth = 1;
+		if( depth > 4 ) depth = 4;
+	}
+	// make `user` stream wait for every step that was issued on the internal streams
+	int join( hipStream_t user )
+	{
+		if( pendingJoin && lastAccum ) MVRT_HIP( hipStreamWaitEvent( user, lastAccum, 0 ) );
+		pendingJoin = false;
+		return 0;
+	}
+	int drain() // host-side: everything the internal streams hold has finished
+	{
+		for( Slot& sl : slots )
+			if( sl.stream ) MVRT_HIP( hipStreamSynchronize( sl.stream ) );
+		pendingJoin = false;
+		return 0;
+	}
+	~mvrt_pt()
+	{
+		for( Slot& sl : slots )
+		{
+			if( sl.stream )
+			{
+				(void)hipStreamSynchronize( sl.stream );
+				(void)hipStreamDestroy( sl.stream );
+			}
+			if( sl.accumDone ) (void)hipEventDestroy( sl.accumDone );
+		}
+		if( forkEv ) (void)hipEventDestroy( forkEv );
 	}
 };
 
@@ -673,6 +720,7 @@ MVRT_EXPORT int mvrt_pt_setup( mvrt_pt* pt, void* stream )
 MVRT_EXPORT int mvrt_pt_set_tile( mvrt_pt* pt, int tileIndex, int tileCount )
 {
 	REQUIRE( pt && tileCount >= 1 && tileIndex >= 0 && tileIndex < tileCount, "bad tile %d of %d", tileIndex, tileCount );
+	if( pt->drain() ) return 1;
 	pt->tileIndex = tileIndex;
 	pt->tileCount = tileCount;
 	pt->width = pt->height = 0; // force re-allocation on the next resize
@@ -681,23 +729,23 @@ MVRT_EXPORT int mvrt_pt_set_tile( mvrt_pt* pt, int tileIndex, int tileCount )
 }
 MVRT_EXPORT uint64_t mvrt_pt_owned_pixels( const mvrt_pt* pt ) { return pt ? pt->ownedPixels : 0; }
 
-static int allocWork( mvrt_pt* pt )
+static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
 	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP;
 	const uint64_t nBlocks = cap / 256 + 2;
-	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays, 4 bytes each;
-	// 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
+	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays + 2 x 8-byte path arrays,
+	// 4 bytes per word; 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
 	const uint64_t words = cap * ( 32 + 6 + 3 + 3 + 4 );
 	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 64 * 256;
-	if( pt->work.alloc( bytes ) ) return 1;
-	uint8_t* base = (uint8_t*)pt->work.p;
+	if( sl.work.alloc( bytes ) ) return 1;
+	uint8_t* base = (uint8_t*)sl.work.p;
 	uint64_t off = 0;
 	auto take = [&]( uint64_t b ) {
 		void* r = base + off;
 		off += ( b + 255 ) & ~(uint64_t)255;
 		return r;
 	};
-	PtBuffers& b = pt->buf;
+	PtBuffers& b = sl.buf;
 	for( int s = 0; s < 2; s++ )
 	{
 		PathSet& ps = b.set[s];
@@ -717,16 +765,58 @@ static int allocWork( mvrt_pt* pt )
 	b.blockCount = (uint32_t*)take( nBlocks * 4 );
 	b.liveCount = (uint32_t*)take( 64 * 4 );
 	b.cursors = (unsigned long long*)take( 16 * 8 );
-	b.stats = (unsigned long long*)take( 16 * 8 );
+	b.stats = pt->statsBuf.as<unsigned long long>(); // shared by all slots (atomic tallies)
 	b.cap = cap;
 	MVRT_HIP( hipMemset( b.liveCount, 0, 64 * 4 ) );
-	MVRT_HIP( hipMemset( b.stats, 0, 16 * 8 ) );
+	return 0;
+}
+static int allocWork( mvrt_pt* pt )
+{
+	if( pt->drain() ) return 1;
+	if( !pt->statsBuf.p )
+	{
+		if( pt->statsBuf.alloc( 16 * 8 ) ) return 1;
+		MVRT_HIP( hipMemset( pt->statsBuf.p, 0, 16 * 8 ) );
+	}
+	if( !pt->forkEv ) MVRT_HIP( hipEventCreateWithFlags( &pt->forkEv, hipEventDisableTiming ) );
+	for( int i = 0; i < 4; i++ )
+	{
+		mvrt_pt::Slot& sl = pt->slots[i];
+		if( i >= pt->depth )
+		{
+			sl.work.release();
+			sl.wsBuf.release();
+			sl.ws = TraceWorkspace{ nullptr, 0, nullptr, nullptr, 0 };
+			memset( &sl.buf, 0, sizeof( sl.buf ) );
+			continue;
+		}
+		if( allocWorkSlot( pt, sl ) ) return 1;
+		if( pt->depth > 1 && !sl.stream ) MVRT_HIP( hipStreamCreateWithFlags( &sl.stream, hipStreamNonBlocking ) );
+		if( !sl.accumDone ) MVRT_HIP( hipEventCreateWithFlags( &sl.accumDone, hipEventDisableTiming ) );
+	}
+	pt->nextSlot = pt->lastSlot = 0;
+	pt->lastAccum = nullptr;
+	return 0;
+}
+static int ensureSlotWorkspace( mvrt_pt* pt, mvrt_pt::Slot& sl )
+{
+	const uint64_t lanes = traceWorkspaceLanes();
+	const uint64_t rows = 2 * (uint64_t)( pt->intersector->info.levels ? pt->intersector->info.levels : 1 ) + 2;
+	const uint64_t bytes = 256 + rows * lanes * sizeof( uint4 );
+	if( sl.wsBuf.bytes < bytes )
+	{
+		if( sl.wsBuf.alloc( bytes ) ) return 1;
+	}
+	sl.ws.cursor = (unsigned long long*)sl.wsBuf.p;
+	sl.ws.spill = (uint4*)( (uint8_t*)sl.wsBuf.p + 256 );
+	sl.ws.spillStride = lanes;
 	return 0;
 }
 
 MVRT_EXPORT int mvrt_pt_clear_framebuffer( mvrt_pt* pt, void* stream )
 {
 	REQUIRE( pt && pt->fbF32.p, "no frame buffer" );
+	if( pt->join( (hipStream_t)stream ) ) return 1;
 	pt->steps = 0; // PathTracer.hpp:100
 	MVRT_HIP( hipMemsetAsync( pt->fbF32.p, 0, pt->fbF32.bytes, (hipStream_t)stream ) );
 	return 0;
@@ -735,6 +825,7 @@ MVRT_EXPORT int mvrt_pt_resize_framebuffer_if_needed( mvrt_pt* pt, void* stream,
 {
 	REQUIRE( pt && width > 0 && height > 0, "bad resolution %dx%d", width, height );
 	if( pt->fbF32.p && pt->width == width && pt->height == height ) return 0;
+	if( pt->drain() ) return 1;
 	const uint64_t nPix = (uint64_t)width * height;
 	const uint64_t nBlocks = ( nPix + MVRT_TILE_PIXELS - 1 ) / MVRT_TILE_PIXELS;
 	// blocks b with b % tileCount == tileIndex
@@ -762,6 +853,7 @@ MVRT_EXPORT int mvrt_pt_load_hdri( mvrt_pt* pt, void* stream, const float* rgbaH
 								   int heightPrimary )
 {
 	REQUIRE( pt && rgbaHost && width > 0 && height > 0, "mvrt_pt_load_hdri: bad image" );
+	if( pt->drain() ) return 1;
 	hipStream_t st = (hipStream_t)stream;
 	const uint64_t n = (uint64_t)width * height;
 	if( pt->hdriPixels.alloc( n * 16 ) ) return 1;
@@ -824,6 +916,7 @@ MVRT_EXPORT int mvrt_pt_update_scene( mvrt_pt* pt, const float* verticesHost, co
 									  const float origin[3], float dps, int gridRes )
 {
 	REQUIRE( pt, "null argument" );
+	if( pt->drain() ) return 1;
 	return mvrt_svo_build( pt->intersector, verticesHost, vcolorsHost, vemissionsHost, nVertices, stream, origin, dps, gridRes );
 }
 MVRT_EXPORT mvrt_svo* mvrt_pt_intersector( mvrt_pt* pt ) { return pt ? pt->intersector : nullptr; }
@@ -842,10 +935,31 @@ MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] 
 	f.ownedPixels = pt->ownedPixels;
 	f.validOwnedPixels = pt->validOwnedPixels;
 	f.iteration = pt->steps++; // PathTracer.hpp:159
-	if( pt->intersector->ensureWorkspace() ) return 1;
-	int rc = launchPtStep( pt->intersector->dev(), pt->intersector->ws, pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, pt->buf, pt->fbF32.as<float4>(), pt->numCUs,
-						   pt->profiling ? &pt->prof : nullptr, (hipStream_t)stream );
-	return rc; // profiling events are collected lazily by mvrt_pt_get_stats (no sync inside step)
+	hipStream_t user = (hipStream_t)stream;
+	mvrt_pt::Slot& sl = pt->slots[pt->nextSlot];
+	pt->lastSlot = pt->nextSlot;
+	pt->nextSlot = ( pt->nextSlot + 1 ) % pt->depth;
+	REQUIRE( sl.buf.cap >= pt->validOwnedPixels * MVRT_SPP_PER_STEP, "internal: work buffers not allocated" );
+	if( ensureSlotWorkspace( pt, sl ) ) return 1;
+	hipStream_t run = user;
+	hipEvent_t after = nullptr;
+	if( pt->depth > 1 )
+	{
+		run = sl.stream;
+		MVRT_HIP( hipEventRecord( pt->forkEv, user ) ); // everything the caller queued so far (clear, upload, ...) comes first
+		MVRT_HIP( hipStreamWaitEvent( run, pt->forkEv, 0 ) );
+		after = pt->lastAccum;
+	}
+	int rc = launchPtStep( pt->intersector->dev(), sl.ws, pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, sl.buf, pt->fbF32.as<float4>(), pt->numCUs,
+						   pt->profiling ? &pt->prof : nullptr, run, after );
+	if( rc ) return rc;
+	if( pt->depth > 1 )
+	{
+		MVRT_HIP( hipEventRecord( sl.accumDone, run ) );
+		pt->lastAccum = sl.accumDone;
+		pt->pendingJoin = true;
+	}
+	return 0; // profiling events are collected lazily by mvrt_pt_get_stats (no sync inside step)
 }
 MVRT_EXPORT int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], const float proj[16], float focus, float lensR )
 {
@@ -856,6 +970,7 @@ MVRT_EXPORT int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float vi
 MVRT_EXPORT int mvrt_pt_resolve( mvrt_pt* pt, void* stream )
 {
 	REQUIRE( pt && pt->fbF32.p, "no frame buffer" );
+	if( pt->join( (hipStream_t)stream ) ) return 1;
 	return launchResolve( pt->fbF32.as<float4>(), pt->validOwnedPixels, pt->fbU8.as<uchar4>(), (hipStream_t)stream );
 }
 MVRT_EXPORT int mvrt_pt_to_image_async( mvrt_pt* pt, void* stream, uint8_t* rgbaHost )
@@ -870,13 +985,32 @@ MVRT_EXPORT uint64_t mvrt_pt_get_octree_bytes( const mvrt_pt* pt ) { return pt ?
 MVRT_EXPORT int mvrt_pt_read_framebuffer( mvrt_pt* pt, void* stream, float* rgbaHost )
 {
 	REQUIRE( pt && pt->fbF32.p, "no frame buffer" );
+	if( pt->join( (hipStream_t)stream ) ) return 1;
 	MVRT_HIP( hipMemcpyAsync( rgbaHost, pt->fbF32.p, pt->ownedPixels * 16, hipMemcpyDeviceToHost, (hipStream_t)stream ) );
 	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
 	return 0;
 }
 MVRT_EXPORT float* mvrt_pt_framebuffer_dev( mvrt_pt* pt ) { return pt ? pt->fbF32.as<float>() : nullptr; }
 MVRT_EXPORT uint8_t* mvrt_pt_framebuffer_u8_dev( mvrt_pt* pt ) { return pt ? pt->fbU8.as<uint8_t>() : nullptr; }
-MVRT_EXPORT const float* mvrt_pt_sample_radiance_dev( mvrt_pt* pt ) { return pt ? pt->buf.Lsx : nullptr; }
+MVRT_EXPORT const float* mvrt_pt_sample_radiance_dev( mvrt_pt* pt )
+{
+	if( !pt ) return nullptr;
+	(void)pt->drain();
+	return pt->slots[pt->lastSlot].buf.Lsx;
+}
+MVRT_EXPORT int mvrt_pt_join( mvrt_pt* pt, void* stream )
+{
+	REQUIRE( pt, "null argument" );
+	return pt->join( (hipStream_t)stream );
+}
+MVRT_EXPORT int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth )
+{
+	REQUIRE( pt && depth >= 1 && depth <= 4, "pipeline depth must be 1..4" );
+	if( pt->drain() ) return 1;
+	pt->depth = depth;
+	if( pt->fbF32.p ) return allocWork( pt );
+	return 0;
+}
 
 MVRT_EXPORT int mvrt_pt_assemble_tiles( const float* gatheredDev, int tileCount, uint64_t rankStridePixels, int width, int height, float* frameDev, void* stream )
 {
@@ -897,6 +1031,7 @@ MVRT_EXPORT int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled )
 MVRT_EXPORT int mvrt_pt_reset_stats( mvrt_pt* pt )
 {
 	REQUIRE( pt, "null argument" );
+	if( pt->drain() ) return 1;
 	if( pt->buf.stats ) MVRT_HIP( hipMemset( pt->buf.stats, 0, 16 * 8 ) );
 	pt->prof.collect();
 	pt->prof.ms[0] = pt->prof.ms[1] = pt->prof.ms[2] = 0.0;
@@ -907,6 +1042,7 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 {
 	REQUIRE( pt && out, "null argument" );
 	memset( out, 0, sizeof( *out ) );
+	if( pt->drain() ) return 1;
 	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) );
 	if( pt->buf.stats )
 	{

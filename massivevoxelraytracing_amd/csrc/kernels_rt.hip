@@ -10,6 +10,7 @@
 #include "traverse_stream.h"
 
 #define WAVE 64
+#define CBLOCK 256 // paths per compaction block
 #define TRACE_BLOCK 64 // one wavefront per workgroup: no barriers, LDS granule = one wave's stack
 
 MVRT_DI uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi( ~0u, __builtin_amdgcn_mbcnt_lo( ~0u, 0u ) ); }
@@ -328,8 +329,6 @@ int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const Came
 // =====================================================================================================
 // Stable compaction: count per 256-item virtual block -> single-workgroup exclusive scan -> rank
 // =====================================================================================================
-#define CBLOCK 256
-
 // number of set flags in each 256-item block
 template <class Pred>
 MVRT_DI void blockCountBody( Pred pred, uint64_t n, uint32_t* __restrict__ blockCount )
@@ -366,10 +365,15 @@ MVRT_DI uint32_t blockRank( bool keep, uint32_t* waveCnt /* LDS, 4 entries */ )
 // exclusive scan of blockCount[0..nBlocks) in place by ONE workgroup of 1024 threads; total -> *totalOut.
 // nBlocks is read from device memory when nDev != null (n = *nDev items).
 __global__ void __launch_bounds__( 1024 ) kScanBlockCounts( uint32_t* __restrict__ blockCount, uint64_t nItemsHost, const uint32_t* __restrict__ nItemsDev,
-															 uint32_t* __restrict__ totalOut )
+															 uint32_t* __restrict__ totalOut, unsigned long long* __restrict__ rayStats = nullptr, int nKinds = 0, int shadowKind = 0 )
 {
 	__shared__ uint32_t part[1024];
 	uint64_t nItems = nItemsDev ? (uint64_t)*nItemsDev : nItemsHost;
+	if( rayStats && threadIdx.x == 0 ) // ray accounting of the stage that was just traced (intersect() calls)
+	{
+		atomicAdd( &rayStats[0], (unsigned long long)nItems * nKinds );
+		if( shadowKind ) atomicAdd( &rayStats[1], (unsigned long long)nItems );
+	}
 	uint32_t nBlocks = (uint32_t)( ( nItems + CBLOCK - 1 ) / CBLOCK );
 	uint32_t per = ( nBlocks + 1023 ) / 1024;
 	uint32_t beg = threadIdx.x * per;
@@ -417,7 +421,7 @@ int launchCompactIndices( const uint8_t* keep, uint64_t n, uint32_t* dstIndex, u
 {
 	int grid = persistentGrid( n, CBLOCK, numCUs(), 8 );
 	hipLaunchKernelGGL( kCountFlags, dim3( grid ), dim3( CBLOCK ), 0, stream, keep, n, blockScratch );
-	hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, blockScratch, n, (const uint32_t*)nullptr, kept );
+	hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, blockScratch, n, (const uint32_t*)nullptr, kept, (unsigned long long*)nullptr, 0, 0 );
 	hipLaunchKernelGGL( kRankFlags, dim3( grid ), dim3( CBLOCK ), 0, stream, keep, n, blockScratch, dstIndex );
 	MVRT_HIP( hipGetLastError() );
 	return 0;
@@ -475,6 +479,7 @@ __global__ void __launch_bounds__( 256 ) kPtGenerate( PtParams P )
 		o.rdy[task] = rd.y;
 		o.rdz[task] = rd.z;
 	}
+	for( uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < ( n + CBLOCK - 1 ) / CBLOCK; b += (uint64_t)gridDim.x * 256 ) P.buf.blockCount[b] = 0u;
 	if( blockIdx.x == 0 && threadIdx.x == 0 )
 	{
 		P.buf.liveCount[0] = (uint32_t)n;
@@ -511,6 +516,7 @@ __global__ void __launch_bounds__( TRACE_BLOCK ) kPtTrace( PtParams P, int stage
 				P.buf.hitT[i] = h.t;
 				P.buf.hitV[i] = h.vIndex;
 				P.buf.hitN[i] = (uint8_t)h.nMajor;
+				if( h.t != MVRT_MAXF ) atomicAdd( &P.buf.blockCount[i / CBLOCK], 1u );
 			}
 			else if( kind == 1 )
 			{
@@ -577,6 +583,7 @@ struct PtIO
 			buf.hitT[i] = h.t;
 			buf.hitPath[i] = h.path;
 			buf.hitN[i] = (uint8_t)h.nMajor;
+			if( isHit ) atomicAdd( &buf.blockCount[i / CBLOCK], 1u ); // survivors per 256-path block (order-free count)
 		}
 		else if( kind == 1 )
 		{
@@ -643,22 +650,6 @@ __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtPara
 		if( dS ) atomicAdd( &P.buf.stats[3], dS );
 		if( nH ) atomicAdd( &P.buf.stats[4], nH );
 	}
-}
-
-// ---- count survivors of a stage per 256-path block (a path survives iff its bounce ray hit) ---------
-__global__ void __launch_bounds__( CBLOCK ) kPtCount( PtParams P, int stage )
-{
-	const uint64_t n = P.buf.liveCount[stage];
-	const float* hitT = P.buf.hitT;
-	blockCountBody( [=]( uint64_t i ) { return hitT[i] != MVRT_MAXF; }, n, P.buf.blockCount );
-}
-
-// single thread: ray accounting for the stage that was just traced
-__global__ void kPtAccountRays( PtParams P, int stage, int nKinds, int shadowKind )
-{
-	unsigned long long n = P.buf.liveCount[stage];
-	atomicAdd( &P.buf.stats[0], n * nKinds );
-	if( shadowKind ) atomicAdd( &P.buf.stats[1], n );
 }
 
 // ---- HDRI lookups (renderCommon.hpp:175-180,354-365,367-465) ---------------------------------------
@@ -839,9 +830,12 @@ __global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int
 		}
 		if( lastStage ) continue; // nothing survives stage 8; uniform across the grid
 		const uint32_t rank = blockRank( alive, waveCnt );
+		const uint32_t blockOffset = P.buf.blockCount[vb];
+		__syncthreads();
+		if( threadIdx.x == 0 ) P.buf.blockCount[vb] = 0u; // the next stage's traversal counts its survivors into it again
 		if( alive )
 		{
-			const uint64_t j = (uint64_t)P.buf.blockCount[vb] + rank;
+			const uint64_t j = (uint64_t)blockOffset + rank;
 			// depth = stage of the reference loop
 			const uint32_t localPixel = task / MVRT_SPP_PER_STEP;
 			const uint32_t spp = P.frame.iteration * MVRT_SPP_PER_STEP + ( task % MVRT_SPP_PER_STEP );
@@ -923,7 +917,7 @@ __global__ void __launch_bounds__( 256 ) kPtAccumulate( PtParams P, float4* __re
 }
 
 int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame,
-				  const PtBuffers& buf, float4* frameBuffer, int nCUs, PtProfiler* prof, hipStream_t stream )
+				  const PtBuffers& buf, float4* frameBuffer, int nCUs, PtProfiler* prof, hipStream_t stream, hipEvent_t accumulateAfter )
 {
 	PtParams P;
 	P.svo = svo;
@@ -974,18 +968,16 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		}
 		PROF_END();
 		PROF_BEGIN( MVRT_K_OTHER );
-		hipLaunchKernelGGL( kPtAccountRays, dim3( 1 ), dim3( 1 ), 0, stream, P, stage, nKinds, shadowKind );
-		if( stage < MVRT_MAX_DEPTH )
-		{
-			hipLaunchKernelGGL( kPtCount, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage );
-			hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, buf.blockCount, (uint64_t)0, (const uint32_t*)( buf.liveCount + stage ),
-								buf.liveCount + stage + 1 );
-		}
+		// survivors per block were counted by the traversal's result stores; scan them (and account the rays)
+		hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, buf.blockCount, (uint64_t)0, (const uint32_t*)( buf.liveCount + stage ),
+							stage < MVRT_MAX_DEPTH ? buf.liveCount + stage + 1 : (uint32_t*)nullptr, buf.stats, nKinds, shadowKind );
 		PROF_END();
 		PROF_BEGIN( MVRT_K_SHADE );
 		hipLaunchKernelGGL( kPtShade, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
 		PROF_END();
 	}
+	// frame-buffer additions must happen in step order (fixed fp32 summation order): wait for the previous step's
+	if( accumulateAfter ) MVRT_HIP( hipStreamWaitEvent( stream, accumulateAfter, 0 ) );
 	PROF_BEGIN( MVRT_K_OTHER );
 	hipLaunchKernelGGL( kPtAccumulate, dim3( persistentGrid( frame.validOwnedPixels, 256, nCUs, 8 ) ), dim3( 256 ), 0, stream, P, frameBuffer );
 	PROF_END();

@@ -75,7 +75,7 @@ struct PtProfiler
 	virtual void end( hipStream_t s ) = 0;
 };
 int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
-				  int numCUs, PtProfiler* prof, hipStream_t stream );
+				  int numCUs, PtProfiler* prof, hipStream_t stream, hipEvent_t accumulateAfter );
 
 int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream );
 int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStridePixels, int W, int H, float4* frame, hipStream_t stream );

@@ -271,3 +271,30 @@ def test_full_hd_frame_properties(mv, O, bunny256_color, hdr):
     assert pt.getSteps() == 0
     pt.step(None, cam)
     assert np.array_equal(pt.read_framebuffer(), fb)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+def test_pipelined_steps_keep_accumulation_order(mv, O, bunny256_color, hdr, depth):
+    """step() calls in flight on internal streams (pipeline depth 1..4) give the same frame buffer bit for bit"""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h, iters = 160, 90, 5
+    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
+    pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    pt.set_pipeline_depth(depth)
+    for _ in range(iters):
+        pt.step(None, cam)
+    got = pt.read_framebuffer()[: w * h]
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb = np.zeros((w * h, 4), np.float32)
+    rays = 0
+    for it in range(iters):
+        fb, _, cnt = sc.render_pt(H, cam, w, h, it, math_mode=1, fb=fb, threads=8)
+        rays += cnt["rays"]
+    assert np.array_equal(got, fb)
+    assert pt.stats()["rays"] == rays
+    # clear + one more step after a pipelined burst
+    pt.clearFrameBuffer(None)
+    pt.step(None, cam)
+    one, _, _ = sc.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
+    assert np.array_equal(pt.read_framebuffer()[: w * h], one)
