@@ -112,8 +112,8 @@ def main():
     def run_steps(k):
         for _ in range(k):
             pt.step(None, cam)
+        pt.join(None)  # step() is deferred/pipelined inside the library: launch and order everything behind the stream
         if dist is not None:
-            pt.join(None)
             mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16)
             mv.synchronize()  # the copy ran on the null stream; RCCL uses torch's stream
             dist.all_gather_into_tensor(gather_out, gather_in)

@@ -146,6 +146,10 @@ int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], cons
  * first makes `stream` wait for the steps in flight; callers that read mvrt_pt_framebuffer_dev() themselves call
  * mvrt_pt_join( pt, stream ) before. */
 int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth );
+/* step() is DEFERRED: up to maxSteps (1 = launch immediately; 0 = automatic, the default: about two full-HD steps of samples per pass) consecutive step() calls are merged into one
+ * wavefront pass -- larger launches, identical per-sample results, additions to the frame buffer still step by step.
+ * Any consumer (resolve, to_image, read, clear, join, get_stats ...) launches what is pending first. */
+int mvrt_pt_set_batch_steps( mvrt_pt* pt, int maxSteps );
 int mvrt_pt_join( mvrt_pt* pt, void* stream );
 int mvrt_pt_resolve( mvrt_pt* pt, void* stream );						/* :130-137, renderResolve */
 int mvrt_pt_to_image_async( mvrt_pt* pt, void* stream, uint8_t* rgbaHost ); /* :118-129 resolve + DtoH (caller syncs) */
@@ -170,6 +174,8 @@ int mvrt_resolve_buffer( const float* rgbaF32Dev, uint64_t nPixels, uint8_t* rgb
 
 /* Per-sample radiance of the LAST step (debug / parity): ownedPixels*16*3 floats on the device */
 const float* mvrt_pt_sample_radiance_dev( mvrt_pt* pt );
+/* host copy of the x, y, z planes (nSamples floats each) of the last pass; sample = (step * pixels + pixel) * 16 + spp */
+int mvrt_pt_read_sample_radiance( mvrt_pt* pt, float* xyzHost, uint64_t nSamples );
 
 /* Counters and timings of the work since the last reset (all steps). */
 typedef struct mvrt_pt_stats

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mvrt_pt_step": (_i32, [_vp, _vp, _vp]),
     "mvrt_pt_step_matrices": (_i32, [_vp, _vp, _vp, _vp, _f32, _f32]),
     "mvrt_pt_set_pipeline_depth": (_i32, [_vp, _i32]),
+    "mvrt_pt_set_batch_steps": (_i32, [_vp, _i32]),
     "mvrt_pt_join": (_i32, [_vp, _vp]),
     "mvrt_pt_resolve": (_i32, [_vp, _vp]),
     "mvrt_pt_to_image_async": (_i32, [_vp, _vp, _vp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "mvrt_pt_assemble_tiles": (_i32, [_vp, _i32, _u64, _i32, _i32, _vp, _vp]),
     "mvrt_resolve_buffer": (_i32, [_vp, _u64, _vp, _vp]),
     "mvrt_pt_sample_radiance_dev": (_vp, [_vp]),
+    "mvrt_pt_read_sample_radiance": (_i32, [_vp, _vp, _u64]),
     "mvrt_pt_set_profiling": (_i32, [_vp, _i32]),
     "mvrt_pt_reset_stats": (_i32, [_vp]),
     "mvrt_pt_get_stats": (_i32, [_vp, _vp, _vp]),
@@ -386,6 +388,9 @@ class PathTracer:
                 cam[13] = lensR
             _check(lib().mvrt_pt_step(self._h, stream, _hp(cam)))
 
+    def set_batch_steps(self, n):
+        _check(lib().mvrt_pt_set_batch_steps(self._h, n))
+
     def set_pipeline_depth(self, depth):
         _check(lib().mvrt_pt_set_pipeline_depth(self._h, depth))
 
@@ -422,14 +427,11 @@ class PathTracer:
     def framebuffer_dev(self):
         return lib().mvrt_pt_framebuffer_dev(self._h)
 
-    def sample_radiance(self):
-        """per-sample radiance of the last step: (ownedPixels*16, 3) host array (debug / parity)"""
-        n = self.owned_pixels() * 16
-        p = lib().mvrt_pt_sample_radiance_dev(self._h)
-        pad = (n * 4 + 255) // 256 * 256
+    def sample_radiance(self, n_samples=None):
+        """per-sample radiance of the last pass: (n, 3) host array (debug / parity)"""
+        n = self.owned_pixels() * 16 if n_samples is None else n_samples
         out = np.zeros((3, n), np.float32)
-        for k in range(3):
-            _check(lib().mvrt_memcpy_d2h(_hp(out[k]), p + k * pad, n * 4, None))
+        _check(lib().mvrt_pt_read_sample_radiance(self._h, _hp(out), n))
         return out.T.copy()
 
     def set_profiling(self, on):

@@ -631,7 +631,13 @@ struct mvrt_pt
 		hipEvent_t accumDone = nullptr;
 	};
 	Slot slots[4];
-	int depth = 2;
+	// deferred execution: up to `batch` consecutive step() calls are merged into ONE wavefront pass (bigger launches,
+	// same per-sample results, frame-buffer additions still in step order).  Flushed by any consumer of the frame.
+	std::vector<CameraPinhole> pendingCams;
+	int pendingIteration = 0;
+	hipStream_t pendingStream = nullptr;
+	int batch = 0; // 0 = automatic: merge steps until a pass holds ~2 full-HD steps worth of samples (see effectiveBatch)
+	int depth = 3;
 	int nextSlot = 0, lastSlot = 0;
 	DevBuf statsBuf;
 	hipEvent_t forkEv = nullptr;
@@ -651,16 +657,38 @@ struct mvrt_pt
 		if( e ) depth = atoi( e );
 		if( depth < 1 ) depth = 1;
 		if( depth > 4 ) depth = 4;
+		const char* b = getenv( "MVRT_BATCH_STEPS" );
+		if( b ) batch = atoi( b );
+		if( batch < 0 ) batch = 0;
+		if( batch > MVRT_MAX_BATCH ) batch = MVRT_MAX_BATCH;
+	}
+	int flush(); // launch the pending steps (defined below)
+	int effectiveBatch() const // merged steps per pass, bounded so that one pass stays below ~160 M samples (~30 GB of path state)
+	{
+		uint64_t perStep = ownedPixels * MVRT_SPP_PER_STEP;
+		if( perStep == 0 ) return 1;
+		int b = batch;
+		if( b == 0 ) // automatic: big enough to amortise launch tails, small enough that several passes can pipeline
+		{
+			b = (int)( ( 66000000ull + perStep / 2 ) / perStep );
+			if( b < 1 ) b = 1;
+			if( b > MVRT_MAX_BATCH ) b = MVRT_MAX_BATCH;
+		}
+		while( b > 1 && perStep * b > 160000000ull ) b--;
+		return b;
 	}
 	// make `user` stream wait for every step that was issued on the internal streams
 	int join( hipStream_t user )
 	{
+		if( flush() ) return 1;
 		if( pendingJoin && lastAccum ) MVRT_HIP( hipStreamWaitEvent( user, lastAccum, 0 ) );
 		pendingJoin = false;
 		return 0;
 	}
 	int drain() // host-side: everything the internal streams hold has finished
 	{
+		if( flush() ) return 1;
+		if( depth == 1 && pendingStream ) MVRT_HIP( hipStreamSynchronize( pendingStream ) );
 		for( Slot& sl : slots )
 			if( sl.stream ) MVRT_HIP( hipStreamSynchronize( sl.stream ) );
 		pendingJoin = false;
@@ -731,7 +759,7 @@ MVRT_EXPORT uint64_t mvrt_pt_owned_pixels( const mvrt_pt* pt ) { return pt ? pt-
 
 static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
-	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP;
+	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP * pt->effectiveBatch();
 	const uint64_t nBlocks = cap / 256 + 2;
 	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays + 2 x 8-byte path arrays,
 	// 4 bytes per word; 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
@@ -934,12 +962,45 @@ MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] 
 	f.tileCount = pt->tileCount;
 	f.ownedPixels = pt->ownedPixels;
 	f.validOwnedPixels = pt->validOwnedPixels;
-	f.iteration = pt->steps++; // PathTracer.hpp:159
-	hipStream_t user = (hipStream_t)stream;
+	(void)f;
+	// deferred: remember the camera; the pass is launched when `batch` steps are pending or a consumer joins
+	if( pt->pendingCams.empty() )
+	{
+		pt->pendingIteration = pt->steps;
+		pt->pendingStream = (hipStream_t)stream;
+	}
+	else if( pt->pendingStream != (hipStream_t)stream )
+	{
+		if( pt->flush() ) return 1;
+		pt->pendingIteration = pt->steps;
+		pt->pendingStream = (hipStream_t)stream;
+	}
+	pt->steps++; // PathTracer.hpp:159
+	pt->pendingCams.push_back( cameraFrom15( camera ) );
+	if( (int)pt->pendingCams.size() >= pt->effectiveBatch() ) return pt->flush();
+	return 0;
+}
+int mvrt_pt::flush()
+{
+	mvrt_pt* pt = this;
+	if( pendingCams.empty() ) return 0;
+	PtFrame f;
+	f.width = width;
+	f.height = height;
+	f.tileIndex = tileIndex;
+	f.tileCount = tileCount;
+	f.ownedPixels = ownedPixels;
+	f.validOwnedPixels = validOwnedPixels;
+	f.iteration = pendingIteration;
+	f.nSteps = (int)pendingCams.size();
+	CameraPinhole cams[MVRT_MAX_BATCH];
+	for( int b = 0; b < f.nSteps; b++ ) cams[b] = pendingCams[b];
+	pendingCams.clear();
+	hipStream_t user = pendingStream;
 	mvrt_pt::Slot& sl = pt->slots[pt->nextSlot];
 	pt->lastSlot = pt->nextSlot;
 	pt->nextSlot = ( pt->nextSlot + 1 ) % pt->depth;
-	REQUIRE( sl.buf.cap >= pt->validOwnedPixels * MVRT_SPP_PER_STEP, "internal: work buffers not allocated" );
+	REQUIRE( sl.buf.cap >= pt->validOwnedPixels * MVRT_SPP_PER_STEP * f.nSteps, "internal: work buffers not allocated" );
 	if( ensureSlotWorkspace( pt, sl ) ) return 1;
 	hipStream_t run = user;
 	hipEvent_t after = nullptr;
@@ -950,7 +1011,7 @@ MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] 
 		MVRT_HIP( hipStreamWaitEvent( run, pt->forkEv, 0 ) );
 		after = pt->lastAccum;
 	}
-	int rc = launchPtStep( pt->intersector->dev(), sl.ws, pt->hdri, pt->pmj.as<float2>(), cameraFrom15( camera ), f, sl.buf, pt->fbF32.as<float4>(), pt->numCUs,
+	int rc = launchPtStep( pt->intersector->dev(), sl.ws, pt->hdri, pt->pmj.as<float2>(), cams, f, sl.buf, pt->fbF32.as<float4>(), pt->numCUs,
 						   pt->profiling ? &pt->prof : nullptr, run, after );
 	if( rc ) return rc;
 	if( pt->depth > 1 )
@@ -998,10 +1059,29 @@ MVRT_EXPORT const float* mvrt_pt_sample_radiance_dev( mvrt_pt* pt )
 	(void)pt->drain();
 	return pt->slots[pt->lastSlot].buf.Lsx;
 }
+MVRT_EXPORT int mvrt_pt_read_sample_radiance( mvrt_pt* pt, float* xyzHost, uint64_t nSamples )
+{
+	REQUIRE( pt && xyzHost, "null argument" );
+	if( pt->drain() ) return 1;
+	const PtBuffers& b = pt->slots[pt->lastSlot].buf;
+	REQUIRE( b.Lsx && nSamples <= b.cap, "no such samples" );
+	MVRT_HIP( hipMemcpy( xyzHost, b.Lsx, nSamples * 4, hipMemcpyDeviceToHost ) );
+	MVRT_HIP( hipMemcpy( xyzHost + nSamples, b.Lsy, nSamples * 4, hipMemcpyDeviceToHost ) );
+	MVRT_HIP( hipMemcpy( xyzHost + 2 * nSamples, b.Lsz, nSamples * 4, hipMemcpyDeviceToHost ) );
+	return 0;
+}
 MVRT_EXPORT int mvrt_pt_join( mvrt_pt* pt, void* stream )
 {
 	REQUIRE( pt, "null argument" );
 	return pt->join( (hipStream_t)stream );
+}
+MVRT_EXPORT int mvrt_pt_set_batch_steps( mvrt_pt* pt, int maxSteps )
+{
+	REQUIRE( pt && maxSteps >= 0 && maxSteps <= MVRT_MAX_BATCH, "batch must be 0 (automatic) or 1..%d", MVRT_MAX_BATCH );
+	if( pt->drain() ) return 1;
+	pt->batch = maxSteps;
+	if( pt->fbF32.p ) return allocWork( pt );
+	return 0;
 }
 MVRT_EXPORT int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth )
 {

@@ -435,7 +435,7 @@ struct PtParams
 	SvoDev svo;
 	HdriDev hdri;
 	const float2* pmj;
-	CameraPinhole cam;
+	CameraPinhole cams[MVRT_MAX_BATCH]; // one camera per merged step
 	PtFrame frame;
 	PtBuffers buf;
 	int hdriEnabled;  // hdri.isEnabled(), renderCommon.hpp:467-470
@@ -450,27 +450,37 @@ MVRT_DI uint32_t globalPixel( const PtFrame& f, uint32_t localPixel )
 	return ( lb * f.tileCount + f.tileIndex ) * MVRT_TILE_PIXELS + ( localPixel % MVRT_TILE_PIXELS );
 }
 
+// sample id ("task") of a batch of nSteps merged steps: ((step * validOwnedPixels + localPixel) * 16 + localSpp)
+MVRT_DI void decodeTask( const PtFrame& f, uint32_t task, uint32_t* step, uint32_t* localPixel, uint32_t* localSpp )
+{
+	const uint32_t ps = task / MVRT_SPP_PER_STEP;
+	*localSpp = task % MVRT_SPP_PER_STEP;
+	const uint32_t vp = (uint32_t)f.validOwnedPixels;
+	*step = ps / vp;
+	*localPixel = ps - *step * vp;
+}
+
 // number of PMJ dimensions consumed before the shading of depth k (voxKernel.cu:662-666,699-700,724,741)
 MVRT_DI int dimBase( int k, int hdriEnabled, int extraSamples ) { return 2 + k * ( ( hdriEnabled ? 2 : 0 ) + 1 ) + ( k > 0 ? extraSamples : 0 ); }
 
 // ---- generate: camera samples -> primary rays (voxKernel.cu:635-667) -------------------------------
 __global__ void __launch_bounds__( 256 ) kPtGenerate( PtParams P )
 {
-	const uint64_t n = P.frame.validOwnedPixels * MVRT_SPP_PER_STEP;
+	const uint64_t n = P.frame.validOwnedPixels * MVRT_SPP_PER_STEP * P.frame.nSteps;
 	const PathSet& o = P.buf.set[0];
 	for( uint64_t task = (uint64_t)blockIdx.x * 256 + threadIdx.x; task < n; task += (uint64_t)gridDim.x * 256 )
 	{
-		uint32_t localPixel = (uint32_t)( task / MVRT_SPP_PER_STEP );
-		uint32_t localSpp = (uint32_t)( task % MVRT_SPP_PER_STEP );
+		uint32_t step, localPixel, localSpp;
+		decodeTask( P.frame, (uint32_t)task, &step, &localPixel, &localSpp );
 		uint32_t pixelIdx = globalPixel( P.frame, localPixel );
 		int x = pixelIdx % P.frame.width;
 		int y = pixelIdx / P.frame.width;
-		uint32_t spp = P.frame.iteration * MVRT_SPP_PER_STEP + localSpp;
+		uint32_t spp = ( P.frame.iteration + step ) * MVRT_SPP_PER_STEP + localSpp; // voxKernel.cu:642
 		uint32_t stream = hashCombine2( 0u, pixelIdx );
 		f2 camU = pmjSample2d( P.pmj, spp, 0, stream );
 		f2 lensU = pmjSample2d( P.pmj, spp, 1, stream );
 		f3 ro, rd;
-		cameraShootThinLens( P.cam, &ro, &rd, x, y, camU.x, camU.y, P.frame.width, P.frame.height, lensU.x, lensU.y );
+		cameraShootThinLens( P.cams[step], &ro, &rd, x, y, camU.x, camU.y, P.frame.width, P.frame.height, lensU.x, lensU.y );
 		o.task[task] = (uint32_t)task;
 		o.rox[task] = ro.x;
 		o.roy[task] = ro.y;
@@ -837,8 +847,9 @@ __global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int
 		{
 			const uint64_t j = (uint64_t)blockOffset + rank;
 			// depth = stage of the reference loop
-			const uint32_t localPixel = task / MVRT_SPP_PER_STEP;
-			const uint32_t spp = P.frame.iteration * MVRT_SPP_PER_STEP + ( task % MVRT_SPP_PER_STEP );
+			uint32_t step, localPixel, localSpp;
+			decodeTask( P.frame, task, &step, &localPixel, &localSpp );
+			const uint32_t spp = ( P.frame.iteration + step ) * MVRT_SPP_PER_STEP + localSpp;
 			const uint32_t stream = hashCombine2( 0u, globalPixel( P.frame, localPixel ) );
 			int dim = dimBase( stage, P.hdriEnabled, P.extraSamples );
 			const f3 R = rawReflectance( P.svo.attrs[vIndex].x ); // :693
@@ -895,35 +906,39 @@ __global__ void __launch_bounds__( 256 ) kPtAccumulate( PtParams P, float4* __re
 	const uint64_t n = P.frame.validOwnedPixels;
 	for( uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256 )
 	{
-		const float4* sx = (const float4*)( P.buf.Lsx + p * MVRT_SPP_PER_STEP );
-		const float4* sy = (const float4*)( P.buf.Lsy + p * MVRT_SPP_PER_STEP );
-		const float4* sz = (const float4*)( P.buf.Lsz + p * MVRT_SPP_PER_STEP );
-		float ax = 0.0f, ay = 0.0f, az = 0.0f;
-#pragma unroll
-		for( int q = 0; q < MVRT_SPP_PER_STEP / 4; q++ )
-		{
-			float4 vx = sx[q], vy = sy[q], vz = sz[q];
-			ax += vx.x; ax += vx.y; ax += vx.z; ax += vx.w;
-			ay += vy.x; ay += vy.y; ay += vy.z; ay += vy.w;
-			az += vz.x; az += vz.y; az += vz.z; az += vz.w;
-		}
 		float4 v = fb[p];
-		v.x += ax;
-		v.y += ay;
-		v.z += az;
-		v.w += (float)MVRT_SPP_PER_STEP;
+		for( int b = 0; b < P.frame.nSteps; b++ ) // merged steps are added one after the other, exactly as separate launches would
+		{
+			const uint64_t base = ( (uint64_t)b * n + p ) * MVRT_SPP_PER_STEP;
+			const float4* sx = (const float4*)( P.buf.Lsx + base );
+			const float4* sy = (const float4*)( P.buf.Lsy + base );
+			const float4* sz = (const float4*)( P.buf.Lsz + base );
+			float ax = 0.0f, ay = 0.0f, az = 0.0f;
+#pragma unroll
+			for( int q = 0; q < MVRT_SPP_PER_STEP / 4; q++ )
+			{
+				float4 vx = sx[q], vy = sy[q], vz = sz[q];
+				ax += vx.x; ax += vx.y; ax += vx.z; ax += vx.w;
+				ay += vy.x; ay += vy.y; ay += vy.z; ay += vy.w;
+				az += vz.x; az += vz.y; az += vz.z; az += vz.w;
+			}
+			v.x += ax;
+			v.y += ay;
+			v.z += az;
+			v.w += (float)MVRT_SPP_PER_STEP;
+		}
 		fb[p] = v;
 	}
 }
 
-int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame,
+int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole* cams, const PtFrame& frame,
 				  const PtBuffers& buf, float4* frameBuffer, int nCUs, PtProfiler* prof, hipStream_t stream, hipEvent_t accumulateAfter )
 {
 	PtParams P;
 	P.svo = svo;
 	P.hdri = hdri;
 	P.pmj = pmj;
-	P.cam = cam;
+	for( int b = 0; b < MVRT_MAX_BATCH; b++ ) P.cams[b] = cams[b < frame.nSteps ? b : 0];
 	P.frame = frame;
 	P.buf = buf;
 	P.hdriEnabled = ( 0.0f < hdri.scale ) ? 1 : 0;
@@ -931,8 +946,13 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 	P.usePaths = ( svo.embedded && ws.spill ) ? 1 : 0;
 	if( nCUs <= 0 ) nCUs = numCUs();
 
-	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP;
+	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP * frame.nSteps;
 	if( nSamples == 0 ) return 0;
+	if( nSamples * 3 >= 0xFFFFFFFFull )
+	{
+		mvrtSetError( "batch too large: %llu samples (ray indices are 32-bit)", (unsigned long long)nSamples );
+		return 1;
+	}
 	if( nSamples > buf.cap )
 	{
 		mvrtSetError( "path buffers too small: %llu samples > capacity %llu", (unsigned long long)nSamples, (unsigned long long)buf.cap );

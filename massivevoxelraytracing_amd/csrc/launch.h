@@ -40,8 +40,10 @@ struct PtFrame
 	int tileIndex, tileCount;
 	uint64_t ownedPixels;	   // padded to whole 256-pixel blocks
 	uint64_t validOwnedPixels; // pixels that exist in the image
-	int iteration;
+	int iteration;			   // iteration of the first step of this batch
+	int nSteps;				   // consecutive step() calls merged into this wavefront pass (1..MVRT_MAX_BATCH)
 };
+#define MVRT_MAX_BATCH 8
 
 // scratch of the persistent traversal kernels (traverse_stream.h): HBM spill rows [level][lane] + a ray cursor.
 // One workspace serves one in-flight launch: calls that share it must be ordered on one stream.
@@ -74,7 +76,7 @@ struct PtProfiler
 	virtual void begin( int kernelClass, hipStream_t s ) = 0;
 	virtual void end( hipStream_t s ) = 0;
 };
-int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole& cam, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
+int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hdri, const float2* pmj, const CameraPinhole* cams /* frame.nSteps */, const PtFrame& frame, const PtBuffers& buf, float4* frameBuffer,
 				  int numCUs, PtProfiler* prof, hipStream_t stream, hipEvent_t accumulateAfter );
 
 int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream );

@@ -298,3 +298,28 @@ def test_pipelined_steps_keep_accumulation_order(mv, O, bunny256_color, hdr, dep
     pt.step(None, cam)
     one, _, _ = sc.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
     assert np.array_equal(pt.read_framebuffer()[: w * h], one)
+
+
+@pytest.mark.parametrize("batch,depth", [(1, 1), (2, 2), (4, 3), (8, 2), (3, 1)])
+def test_deferred_batched_steps_with_moving_camera(mv, O, bunny256_color, hdr, batch, depth):
+    """step() calls merged into one wavefront pass (batch) and pipelined (depth): every step keeps its own camera and
+    iteration index, and the frame buffer equals step-by-step accumulation bit for bit"""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h, iters = 96, 54, 7
+    cams = [probe_camera(sc.origin, sc.dps, 256, focus=9.0 + 0.1 * i, lens_r=0.02 * i, offset=(6 - 0.2 * i, 4, 6 + 0.1 * i)) for i in range(iters)]
+    pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    pt.set_batch_steps(batch)
+    pt.set_pipeline_depth(depth)
+    for c in cams:
+        pt.step(None, c)
+    assert pt.getSteps() == iters
+    got = pt.read_framebuffer()[: w * h]
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb = np.zeros((w * h, 4), np.float32)
+    rays = 0
+    for it, c in enumerate(cams):
+        fb, _, cnt = sc.render_pt(H, c, w, h, it, math_mode=1, fb=fb, threads=8)
+        rays += cnt["rays"]
+    assert np.array_equal(got, fb)
+    assert pt.stats()["rays"] == rays
