@@ -764,7 +764,7 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays + 2 x 8-byte path arrays,
 	// 4 bytes per word; 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
 	const uint64_t words = cap * ( 32 + 6 + 3 + 3 + 4 );
-	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 64 * 256;
+	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 1024 + 64 * 256;
 	if( sl.work.alloc( bytes ) ) return 1;
 	uint8_t* base = (uint8_t*)sl.work.p;
 	uint64_t off = 0;
@@ -795,7 +795,9 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	b.cursors = (unsigned long long*)take( 16 * 8 );
 	b.stats = pt->statsBuf.as<unsigned long long>(); // shared by all slots (atomic tallies)
 	b.cap = cap;
+	b.selfDev = (const PtBuffers*)take( sizeof( PtBuffers ) );
 	MVRT_HIP( hipMemset( b.liveCount, 0, 64 * 4 ) );
+	MVRT_HIP( hipMemcpy( (void*)b.selfDev, &b, sizeof( PtBuffers ), hipMemcpyHostToDevice ) );
 	return 0;
 }
 static int allocWork( mvrt_pt* pt )

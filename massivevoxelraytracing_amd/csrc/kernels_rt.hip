@@ -127,8 +127,11 @@ static uint32_t streamChunk( uint64_t total, uint64_t waves )
 {
 	uint64_t c = total / ( waves * 4 );
 	c = ( c + 63 ) / 64 * 64;
+#ifndef MVRT_CHUNK_MAX
+#define MVRT_CHUNK_MAX 1024
+#endif
 	if( c < 64 ) c = 64;
-	if( c > 1024 ) c = 1024;
+	if( c > MVRT_CHUNK_MAX ) c = MVRT_CHUNK_MAX;
 	return (uint32_t)c;
 }
 static int streamGrid( uint64_t total, int nCUs )
@@ -557,10 +560,20 @@ __global__ void __launch_bounds__( TRACE_BLOCK ) kPtTrace( PtParams P, int stage
 	}
 }
 
+// Opaque view of a kernarg pointer: the asm makes the value unknown to the optimiser at this point, so the ~25 array
+// pointers read through it are (re)loaded with scalar loads where they are used -- at refill time -- instead of being
+// hoisted out of the traversal loop, where they would occupy ~60 SGPRs and push the node pointer out of registers.
+template <class T>
+MVRT_DI const T* opaquePtr( const T* p )
+{
+	asm volatile( "" : "+s"( p ) );
+	return p;
+}
+
 struct PtIO
 {
-	PtBuffers buf;
-	const PathSet* in;
+	const PtBuffers* table; // device-resident pointer table (read through opaquePtr)
+	int setIdx;
 	uint32_t n;
 	int shadowKind;
 #ifdef MVRT_UTIL_STATS
@@ -575,16 +588,19 @@ struct PtIO
 	}
 	MVRT_DI bool load( uint32_t r, f3* ro, f3* rd ) const
 	{
+		const PtBuffers& buf = *opaquePtr( table );
+		const PathSet& in = buf.set[setIdx];
 		uint32_t i;
 		const int kind = kindOf( r, &i );
-		*ro = mk3( in->rox[i], in->roy[i], in->roz[i] );
-		if( kind == 0 ) *rd = mk3( in->rdx[i], in->rdy[i], in->rdz[i] );
+		*ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
+		if( kind == 0 ) *rd = mk3( in.rdx[i], in.rdy[i], in.rdz[i] );
 		else if( kind == 1 ) *rd = mk3( buf.sx[i], buf.sy[i], buf.sz[i] );
 		else *rd = mk3( buf.ex[i], buf.ey[i], buf.ez[i] );
 		return kind == 1;
 	}
 	MVRT_DI void store( uint32_t r, const StreamHit& h, bool )
 	{
+		const PtBuffers& buf = *opaquePtr( table );
 		uint32_t i;
 		const int kind = kindOf( r, &i );
 		const bool isHit = h.t != MVRT_MAXF;
@@ -616,8 +632,8 @@ __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtPara
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
 	PtIO io;
-	io.buf = P.buf;
-	io.in = &P.buf.set[setIdx];
+	io.table = P.buf.selfDev;
+	io.setIdx = setIdx;
 	io.n = P.buf.liveCount[stage];
 	io.shadowKind = shadowKind;
 	io.dNormal = io.dShadow = io.nHits = 0;

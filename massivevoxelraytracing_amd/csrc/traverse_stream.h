@@ -238,7 +238,8 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					if( chunkNext == chunkEnd )
 					{
 						unsigned long long base = 0;
-						if( lane == 0 ) base = atomicAdd( cursor, (unsigned long long)chunk );
+						const uint32_t c = chunk;
+						if( lane == 0 ) base = atomicAdd( cursor, (unsigned long long)c );
 						base = __shfl( base, 0, 64 );
 						if( base >= total )
 						{
@@ -246,7 +247,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 							break;
 						}
 						chunkNext = (uint32_t)base;
-						chunkEnd = ( total - chunkNext ) < chunk ? total : chunkNext + chunk;
+						chunkEnd = ( total - chunkNext ) < c ? total : chunkNext + c;
 					}
 					const uint32_t avail = chunkEnd - chunkNext;
 					const uint32_t take = avail < need ? avail : need;
