@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--mode", default="pt", choices=["pt", "primary"], help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2)")
     ap.add_argument("--emulate-tiles", type=int, default=0, help="diagnostic: render only tile 0 of N on one GPU (predicts per-rank time of an N-GPU run)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
@@ -102,6 +103,23 @@ def main():
     cam = scenes.look_at_camera(eye, centre, 40.0, focus, 0.02)
     setup_s = time.time() - t_setup
 
+    if args.mode == "primary":
+        # BASELINE.json configs[1]: primary-ray cast (the `render` kernel, voxKernel.cu:437-483) through pixel centres
+        svo = pt.m_intersectorOctreeGPU
+        rgba_dev = mv.DeviceArray((W * H, 4), np.uint8)
+        for _ in range(args.warmup):
+            svo.render_device(cam, W, H, True, rgba_dev)
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            svo.render_device(cam, W, H, True, rgba_dev)
+        barrier_sync()
+        el = time.perf_counter() - t0
+        print(json.dumps({"metric": "Mrays/sec (primary) at %dx%d" % (W, H), "value": round(W * H * args.steps / el / 1e6, 2), "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "%s stand-in %d^3 SVO, primary-ray cast with voxel colours (render kernel), %dx%d" % (args.scene, args.grid_res, W, H),
+                                                          "voxels": int(info.numberOfVoxels), "dag_nodes": int(info.numberOfNodes)}}), flush=True)
+        return
     owned = pt.owned_pixels()
     gather_in = gather_out = frame = None
     if dist is not None:
@@ -158,7 +176,7 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": "kPtTraceStream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": int(traffic["traffic_bytes_per_launch"]) if traffic else None, "traffic_source": traffic["_source"] if traffic else None,
+            "traffic": int(traffic["traffic_bytes_per_ray"] * st["rays"] / launches) if traffic else None, "traffic_source": traffic["_source"] if traffic else None,
             "algorithmic_bytes_per_launch": int(algo_bytes / launches), "avg_launch_ms": round(trace_ms / launches, 4), "launches": launches,
             "bytes_per_ray": round(algo_bytes / max(st["rays"], 1), 2),
             "descents_per_ray": round((st["descents"] + st["shadowDescents"]) / max(st["rays"], 1), 2),
