@@ -52,5 +52,21 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_apps(verbose=True):
+    """g++ the C++ host applications that sit on the header-only mirrors (apps/) against libmvrt_hip.so."""
+    root = os.path.dirname(HERE)
+    out = os.path.join(root, "apps", "rtcamp_batch")
+    src = os.path.join(root, "apps", "rtcamp_batch.cpp")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(root, "apps", "scene_io.hpp"))):
+        return out
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "apps"), src, "-o", out,
+           "-L", HERE, "-l:libmvrt_hip.so", "-Wl,-rpath," + HERE, "-Wl,--allow-shlib-undefined"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_apps()
