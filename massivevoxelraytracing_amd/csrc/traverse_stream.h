@@ -76,8 +76,20 @@ MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
 	return c;
 }
 
-MVRT_DI uint32_t bitMask( uint32_t v, uint32_t bit ) { return (uint32_t)__builtin_amdgcn_sbfe( (int)v, bit, 1 ); } // 0 or 0xFFFFFFFF
-MVRT_DI uint32_t bfi( uint32_t mask, uint32_t a, uint32_t b ) { return ( a & mask ) | ( b & ~mask ); }			   // v_bfi_b32
+// Single-instruction helpers through inline asm: written as plain C the optimiser turns these mask selects back into
+// v_cmp + v_cndmask pairs (two VALU slots and a VCC hazard each); the kernel is VALU-issue bound, so the forms matter.
+MVRT_DI uint32_t bitMask( uint32_t v, uint32_t bit ) // 0 or 0xFFFFFFFF from bit `bit` of v (v_bfe_i32)
+{
+	uint32_t r;
+	asm( "v_bfe_i32 %0, %1, %2, 1" : "=v"( r ) : "v"( v ), "v"( bit ) );
+	return r;
+}
+MVRT_DI uint32_t bfi( uint32_t mask, uint32_t a, uint32_t b ) // (a & mask) | (b & ~mask)  (v_bfi_b32)
+{
+	uint32_t r;
+	asm( "v_bfi_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( mask ), "v"( a ), "v"( b ) );
+	return r;
+}
 
 
 // Exact-emulation path for IRREGULAR rays: a direction component of exactly zero makes the reference's slab
@@ -361,7 +373,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			// first visit: childMask bit = (tM < S) = sign bit of (tM - S)  (:342-348; the difference of two
 			// distinct floats is never zero with denormals on, and x - x = +0)
 			const uint32_t cmInit = ( mvrt_f2u( txM - S ) >> 31 ) | ( ( mvrt_f2u( tyM - S ) >> 30 ) & 2u ) | ( ( mvrt_f2u( tzM - S ) >> 29 ) & 4u );
-			const uint32_t cm = bfi( bitMask( childMask, 3 ), cmInit, childMask & 7u );
+			const uint32_t cm = bfi( bitMask( childMask, 3 ), cmInit, childMask ); // childMask is either 8 (first visit) or a 3-bit mask
 			const float x1 = mvrt_u2f( bfi( bitMask( cm, 0 ), mvrt_f2u( tx1 ), mvrt_f2u( txM ) ) ); // :358-360
 			const float y1 = mvrt_u2f( bfi( bitMask( cm, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
 			const float z1 = mvrt_u2f( bfi( bitMask( cm, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
@@ -392,14 +404,17 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					}
 					uint4 e;
 					e.x = node;
-					e.y = ( mvrt_f2u( tx1 ) & 0x7FFFFFFFu ) | ( nextMask << 31 );
-					e.z = ( mvrt_f2u( ty1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 2u ) << 30 );
-					e.w = ( mvrt_f2u( tz1 ) & 0x7FFFFFFFu ) | ( ( nextMask & 4u ) << 29 );
+					// sign bits of a saved node's exit times are clear (entered with min >= 0; +0 - x and 0.5*(a+b) never
+					// yield -0.0 from non-negative-zero inputs), so the child mask can be OR-ed in without masking
+					e.y = mvrt_f2u( tx1 ) | ( nextMask << 31 );
+					e.z = mvrt_f2u( ty1 ) | ( ( nextMask & 2u ) << 30 );
+					e.w = mvrt_f2u( tz1 ) | ( ( nextMask & 4u ) << 29 );
 					myRing[slot * 64] = e;
 					pending |= 1u << level;
 					inLds |= 1u << level;
 				}
-				node = nodes[node & 0xFFFFFFu].children[childIndex]; // :381
+				// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
+				node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
 				descents++;
 				path = ( path << 3 ) | childIndex;
 				tx1 = x1; // :382-386
