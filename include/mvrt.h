@@ -78,6 +78,20 @@ int mvrt_svo_destroy( mvrt_svo* svo ); /* IntersectorOctreeGPU::cleanUp, :26-38 
 int mvrt_svo_build( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
 					const float origin[3], float dps, int gridRes );
 
+/* Same with options.  MVRT_BUILD_NO_DAG: every sibling group becomes a node (the reference with ENABLE_GPU_DAG off,
+ * voxKernel.cu:322-334; node numbering = deterministic group order).  MVRT_BUILD_NO_EMBEDDED_MASK: child pointers stay
+ * plain indices and a node's mask is read from the node (voxCommon.hpp:353-356); chosen automatically when the octree has
+ * >= 0xFFFFFF nodes, the limit of the embedded form (IntersectorOctreeGPU.hpp:231). */
+#define MVRT_BUILD_NO_DAG 1
+#define MVRT_BUILD_NO_EMBEDDED_MASK 2
+int mvrt_svo_build_ex( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
+					   const float origin[3], float dps, int gridRes, int flags );
+/* Seeded synthetic octree for HBM-bound stress runs (BASELINE.json configs[4]): nRandomVoxels uniformly random cells of the
+ * gridRes^3 grid (duplicates merge), hash-derived colours, ~1/256 emissive; generated, sorted and built on the GPU.
+ * voxel i: h = splitmix64(seed + i); x = h & (res-1), y = (h >> 21) & (res-1), z = (h >> 42) & (res-1); c = splitmix64(h):
+ * colour = (c & 0xFFFFFF) | 0x404040, emission = colour if (c >> 56) == 0 else 0. */
+int mvrt_svo_build_synthetic( mvrt_svo* svo, int gridRes, uint64_t nRandomVoxels, uint64_t seed, const float origin[3], float dps, int flags, void* stream );
+
 /* Adopt an SVO built elsewhere (e.g. IntersectorOctree::buildDAGReference on the CPU, IntersectorOctree.hpp:
  * 224-231): nodes in the reference's 68-byte layout, root last.  embeddedMask = 0 selects the variant where
  * the mask is fetched from the node (voxCommon.hpp:353-356; required above 0xFFFFFF nodes). */

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mvrt_svo_create": (_i32, [_vp]),
     "mvrt_svo_destroy": (_i32, [_vp]),
     "mvrt_svo_build": (_i32, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _f32, _i32]),
+    "mvrt_svo_build_ex": (_i32, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _f32, _i32, _i32]),
+    "mvrt_svo_build_synthetic": (_i32, [_vp, _i32, _u64, _u64, _vp, _f32, _i32, _vp]),
     "mvrt_svo_upload": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp, _f32, _i32, _i32, _i32, _vp]),
     "mvrt_svo_get_info": (_i32, [_vp, _vp]),
     "mvrt_svo_set_emission_scale": (_i32, [_vp, _f32]),
@@ -225,14 +227,23 @@ class IntersectorOctreeGPU:
 
     __del__ = cleanUp
 
-    def build(self, vertices, vcolors, vemissions, stream, origin, dps, gridRes):
+    BUILD_NO_DAG = 1
+    BUILD_NO_EMBEDDED_MASK = 2
+
+    def build_synthetic(self, gridRes, n_random_voxels, seed, origin=(0.0, 0.0, 0.0), dps=None, flags=0, stream=None):
+        """seeded random-voxel octree built on the GPU (HBM-bound stress, mvrt_svo_build_synthetic)"""
+        o = np.ascontiguousarray(origin, np.float32)
+        dps = np.float32(1.0 / gridRes) if dps is None else np.float32(dps)
+        _check(lib().mvrt_svo_build_synthetic(self._h, int(gridRes), int(n_random_voxels), int(seed), _hp(o), float(dps), int(flags), stream))
+
+    def build(self, vertices, vcolors, vemissions, stream, origin, dps, gridRes, flags=0):
         """IntersectorOctreeGPU::build(vertices, vcolors, vemissions, Shader*, stream, origin, dps, gridRes)
         (:40-47; the Shader* argument has no counterpart -- kernels are precompiled)."""
         v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
         c = None if vcolors is None else np.ascontiguousarray(vcolors, np.float32).reshape(-1, 3)
         e = None if vemissions is None else np.ascontiguousarray(vemissions, np.float32).reshape(-1, 3)
         o = np.ascontiguousarray(origin, np.float32)
-        _check(lib().mvrt_svo_build(self._h, _hp(v), _hp(c), _hp(e), len(v), stream, _hp(o), float(np.float32(dps)), int(gridRes)))
+        _check(lib().mvrt_svo_build_ex(self._h, _hp(v), _hp(c), _hp(e), len(v), stream, _hp(o), float(np.float32(dps)), int(gridRes), int(flags)))
 
     def upload(self, nodes68, attribs, origin, dps, gridRes, hasEmission=0, embeddedMask=True, stream=None):
         nodes68 = np.ascontiguousarray(nodes68)

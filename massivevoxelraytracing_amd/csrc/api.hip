@@ -250,7 +250,7 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	MVRT_HIP( hipMalloc( (void**)&svo->masks, numberOfNodes ) );
 	MVRT_HIP( hipMalloc( (void**)&svo->attrs, (uint64_t)( numberOfVoxels ? numberOfVoxels : 1 ) * 8 ) );
 	if( numberOfVoxels ) MVRT_HIP( hipMemcpyAsync( svo->attrs, attribs8Host, (uint64_t)numberOfVoxels * 8, hipMemcpyHostToDevice, st ) );
-	if( launchConvertNodes( raw.as<uint8_t>(), numberOfNodes, svo->nodes, svo->masks, st ) ) return 1;
+	if( launchConvertNodes( raw.as<uint8_t>(), numberOfNodes, svo->nodes, svo->masks, embeddedMask ? 0 : 1, st ) ) return 1;
 	svo->info.numberOfNodes = numberOfNodes;
 	svo->info.numberOfVoxels = numberOfVoxels;
 	svo->info.hasEmission = hasEmission ? 1 : 0;
@@ -262,17 +262,8 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	return 0;
 }
 
-MVRT_EXPORT int mvrt_svo_build( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
-								const float origin[3], float dps, int gridRes )
+static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origin[3], float dps, int gridRes )
 {
-	REQUIRE( svo && verticesHost && nVertices >= 3 && nVertices % 3 == 0, "mvrt_svo_build: need 3*k vertices" );
-	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
-	hipStream_t st = (hipStream_t)stream;
-	svo->cleanUp(); // :53
-	SvoBuildResult r;
-	memset( &r, 0, sizeof( r ) );
-	if( svoBuildFromTriangles( verticesHost, vcolorsHost, vemissionsHost, nVertices, mk3( origin[0], origin[1], origin[2] ), dps, gridRes, st, &r ) ) return 1;
-	REQUIRE( r.nNodes < 0xFFFFFFu, "octree has %u nodes; embedded masks need fewer than 0xFFFFFF (IntersectorOctreeGPU.hpp:231)", r.nNodes );
 	svo->nodes = r.nodes;
 	svo->masks = r.masks;
 	svo->attrs = r.attrs;
@@ -280,11 +271,38 @@ MVRT_EXPORT int mvrt_svo_build( mvrt_svo* svo, const float* verticesHost, const 
 	svo->info.numberOfNodes = r.nNodes;
 	svo->info.numberOfVoxels = r.nVoxels;
 	svo->info.hasEmission = r.hasEmission;
-	svo->info.embeddedMask = 1;
+	svo->info.embeddedMask = r.embedded; // 0 when the octree has >= 0xFFFFFF nodes (IntersectorOctreeGPU.hpp:231) or on request
 	svo->info.totalDumpedVoxels = r.totalDumped;
 	setBounds( svo, origin, dps, gridRes );
 	MVRT_HIP( hipMemcpy( &svo->rootMask, svo->masks + ( r.nNodes - 1 ), 1, hipMemcpyDeviceToHost ) );
 	return 0;
+}
+MVRT_EXPORT int mvrt_svo_build_ex( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
+								   const float origin[3], float dps, int gridRes, int flags )
+{
+	REQUIRE( svo && verticesHost && nVertices >= 3 && nVertices % 3 == 0, "mvrt_svo_build: need 3*k vertices" );
+	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
+	hipStream_t st = (hipStream_t)stream;
+	svo->cleanUp(); // :53
+	SvoBuildResult r;
+	memset( &r, 0, sizeof( r ) );
+	if( svoBuildFromTriangles( verticesHost, vcolorsHost, vemissionsHost, nVertices, mk3( origin[0], origin[1], origin[2] ), dps, gridRes, flags, st, &r ) ) return 1;
+	return adoptBuild( svo, r, origin, dps, gridRes );
+}
+MVRT_EXPORT int mvrt_svo_build( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
+								const float origin[3], float dps, int gridRes )
+{
+	return mvrt_svo_build_ex( svo, verticesHost, vcolorsHost, vemissionsHost, nVertices, stream, origin, dps, gridRes, 0 );
+}
+MVRT_EXPORT int mvrt_svo_build_synthetic( mvrt_svo* svo, int gridRes, uint64_t nRandomVoxels, uint64_t seed, const float origin[3], float dps, int flags, void* stream )
+{
+	REQUIRE( svo, "null argument" );
+	REQUIRE( ilog2Exact( gridRes ) > 0 && gridRes <= ( 1 << 21 ), "gridRes %d is not a power of two in [2, 2^21]", gridRes );
+	svo->cleanUp();
+	SvoBuildResult r;
+	memset( &r, 0, sizeof( r ) );
+	if( svoBuildSynthetic( nRandomVoxels, seed, gridRes, flags, (hipStream_t)stream, &r ) ) return 1;
+	return adoptBuild( svo, r, origin, dps, gridRes );
 }
 
 MVRT_EXPORT int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info )
@@ -307,7 +325,7 @@ MVRT_EXPORT int mvrt_svo_download( const mvrt_svo* svo, void* nodes68Host, void*
 	{
 		DevBuf raw;
 		if( raw.alloc( (uint64_t)svo->info.numberOfNodes * 68 ) ) return 1;
-		if( launchNodesTo68( svo->nodes, svo->masks, svo->info.numberOfNodes, raw.as<uint8_t>(), st ) ) return 1;
+		if( launchNodesTo68( svo->nodes, svo->masks, svo->info.numberOfNodes, raw.as<uint8_t>(), svo->info.embeddedMask ? 0 : 1, st ) ) return 1;
 		MVRT_HIP( hipMemcpyAsync( nodes68Host, raw.p, raw.bytes, hipMemcpyDeviceToHost, st ) );
 		MVRT_HIP( hipStreamSynchronize( st ) );
 	}

@@ -70,10 +70,11 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 		}
 	}
 }
+template <bool EMBED>
 __global__ void __launch_bounds__( 64 ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	traceStream( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	traceStream<EMBED>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
 }
 
 struct PrimaryIO
@@ -117,10 +118,11 @@ struct PrimaryIO
 		if( descentsOut ) descentsOut[pixelIdx] = r.descents;
 	}
 };
+template <bool EMBED>
 __global__ void __launch_bounds__( 64 ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	traceStream( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	traceStream<EMBED>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
 }
 
 static uint32_t streamChunk( uint64_t total, uint64_t waves )
@@ -218,7 +220,7 @@ int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, c
 					  const float* rdz, const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
 {
 	if( n == 0 ) return 0;
-	if( svo.embedded && ws.spill )
+	if( ws.spill )
 	{
 		uint64_t* paths = vIndex ? ws.paths : nullptr;
 		if( vIndex && ws.pathCap < n )
@@ -229,7 +231,8 @@ int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, c
 		BatchIO io = { rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, paths, descents };
 		int grid = streamGrid( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
-		hipLaunchKernelGGL( kTraceBatchStream, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		if( svo.embedded ) hipLaunchKernelGGL( kTraceBatchStream<true>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		else hipLaunchKernelGGL( kTraceBatchStream<false>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
 		if( vIndex )
 			hipLaunchKernelGGL( kResolveVIndex, dim3( persistentGrid( n, 256, numCUs(), 8 ) ), dim3( 256 ), 0, stream, svo, n, t, paths, isShadow, vIndex, (uchar4*)nullptr );
 		MVRT_HIP( hipGetLastError() );
@@ -292,7 +295,7 @@ int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const Came
 {
 	uint64_t n = (uint64_t)W * H;
 	if( n == 0 ) return 0;
-	if( svo.embedded && ws.spill )
+	if( ws.spill )
 	{
 		PrimaryIO io;
 		io.svo = svo;
@@ -314,7 +317,8 @@ int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const Came
 		io.rdKeep = mk3( 0, 0, 0 );
 		int grid = streamGrid( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
-		hipLaunchKernelGGL( kRenderPrimaryStream, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		if( svo.embedded ) hipLaunchKernelGGL( kRenderPrimaryStream<true>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		else hipLaunchKernelGGL( kRenderPrimaryStream<false>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
 		if( needPaths )
 			hipLaunchKernelGGL( kResolveVIndex, dim3( persistentGrid( n, 256, numCUs(), 8 ) ), dim3( 256 ), 0, stream, svo, n, t, ws.paths, (const uint8_t*)nullptr, vIndex,
 								showVertexColor ? rgba : (uchar4*)nullptr );
@@ -628,6 +632,7 @@ struct PtIO
 #ifndef MVRT_TRACE_WAVES
 #define MVRT_TRACE_WAVES 1
 #endif
+template <bool EMBED>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
@@ -659,7 +664,7 @@ __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtPara
 	c = ( c + 63 ) / 64 * 64;
 	if( c < 64 ) c = 64;
 	if( c > chunk ) c = chunk;
-	traceStream( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	traceStream<EMBED>( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
 	unsigned long long dN = waveSum( (unsigned long long)io.dNormal ), dS = waveSum( (unsigned long long)io.dShadow ), nH = waveSum( (unsigned long long)io.nHits );
 #ifdef MVRT_UTIL_STATS
 	if( threadIdx.x == 0 )
@@ -959,7 +964,7 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 	P.buf = buf;
 	P.hdriEnabled = ( 0.0f < hdri.scale ) ? 1 : 0;
 	P.extraSamples = svo.hasEmission ? 1 : 0;
-	P.usePaths = ( svo.embedded && ws.spill ) ? 1 : 0;
+	P.usePaths = ws.spill ? 1 : 0;
 	if( nCUs <= 0 ) nCUs = numCUs();
 
 	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP * frame.nSteps;
@@ -993,10 +998,13 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		// upper bound for the grid: every stage has at most nSamples live paths
 		const int traceGrid = persistentGrid( nSamples * nKinds, TRACE_BLOCK, nCUs, 32 );
 		PROF_BEGIN( MVRT_K_TRACE );
-		if( svo.embedded && ws.spill )
+		if( ws.spill )
 		{
 			const int g = streamGrid( nSamples * nKinds, nCUs );
-			hipLaunchKernelGGL( kPtTraceStream, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
+			if( svo.embedded )
+				hipLaunchKernelGGL( kPtTraceStream<true>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
+			else
+				hipLaunchKernelGGL( kPtTraceStream<false>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
 		}
 		else
 		{

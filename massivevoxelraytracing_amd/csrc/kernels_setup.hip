@@ -3,7 +3,7 @@
 #include "launch.h"
 
 // ---- reference 68-byte AoS nodes <-> one 64-byte line per node -----------------------------------------
-__global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restrict__ nodes68, uint32_t nNodes, Node64* __restrict__ out, uint8_t* __restrict__ masks )
+__global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restrict__ nodes68, uint32_t nNodes, Node64* __restrict__ out, uint8_t* __restrict__ masks, int maskInPsum0 )
 {
 	// one thread per (node, dword): 16 payload dwords per node
 	uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -11,29 +11,33 @@ __global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restric
 	uint32_t w = gid % 16;
 	if( node >= nNodes ) return;
 	const uint32_t* src = (const uint32_t*)( nodes68 + node * 68 ); // 68 is a multiple of 4: aligned dwords
-	( (uint32_t*)( out + node ) )[w] = src[1 + w];
+	uint32_t v = src[1 + w];
+	if( maskInPsum0 && w == 8 ) v = src[0] & 0xFF; // psum[0] (== 0) carries the node's own mask in the non-embedded flavour
+	( (uint32_t*)( out + node ) )[w] = v;
 	if( w == 0 ) masks[node] = (uint8_t)( src[0] & 0xFF );
 }
-int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, hipStream_t stream )
+int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, int maskInPsum0, hipStream_t stream )
 {
 	if( nNodes == 0 ) return 0;
-	hipLaunchKernelGGL( kConvertNodes, dim3( divUp( (uint64_t)nNodes * 16, 256 ) ), dim3( 256 ), 0, stream, nodes68, nNodes, out, masks );
+	hipLaunchKernelGGL( kConvertNodes, dim3( divUp( (uint64_t)nNodes * 16, 256 ) ), dim3( 256 ), 0, stream, nodes68, nNodes, out, masks, maskInPsum0 );
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
-__global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint32_t nNodes, uint8_t* __restrict__ nodes68 )
+__global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint32_t nNodes, uint8_t* __restrict__ nodes68, int maskInPsum0 )
 {
 	uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	uint64_t node = gid / 17;
 	uint32_t w = gid % 17;
 	if( node >= nNodes ) return;
 	uint32_t* dst = (uint32_t*)( nodes68 + node * 68 );
-	dst[w] = w == 0 ? (uint32_t)masks[node] : ( (const uint32_t*)( nodes + node ) )[w - 1];
+	uint32_t v = w == 0 ? (uint32_t)masks[node] : ( (const uint32_t*)( nodes + node ) )[w - 1];
+	if( maskInPsum0 && w == 9 ) v = 0; // reference layout: nVoxelsPSum[0] == 0
+	dst[w] = v;
 }
-int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, hipStream_t stream )
+int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, int maskInPsum0, hipStream_t stream )
 {
 	if( nNodes == 0 ) return 0;
-	hipLaunchKernelGGL( kNodesTo68, dim3( divUp( (uint64_t)nNodes * 17, 256 ) ), dim3( 256 ), 0, stream, nodes, masks, nNodes, nodes68 );
+	hipLaunchKernelGGL( kNodesTo68, dim3( divUp( (uint64_t)nNodes * 17, 256 ) ), dim3( 256 ), 0, stream, nodes, masks, nNodes, nodes68, maskInPsum0 );
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }

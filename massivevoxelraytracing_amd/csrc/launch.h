@@ -82,8 +82,8 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 
 int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream );
 int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStridePixels, int W, int H, float4* frame, hipStream_t stream );
-int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, hipStream_t stream );
-int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, hipStream_t stream );
+int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, int maskInPsum0, hipStream_t stream );
+int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, int maskInPsum0, hipStream_t stream );
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 
 // GPU SVO construction (svo_build.hip)
@@ -93,8 +93,10 @@ struct SvoBuildResult
 	uint8_t* masks;
 	uint2* attrs;
 	uint64_t* morton; // kept for parity checks (sorted unique codes)
-	uint32_t nNodes, nVoxels, hasEmission;
+	uint32_t nNodes, nVoxels, hasEmission, embedded;
 	uint64_t totalDumped;
 };
-int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const float* emisHost, uint64_t nVertices, f3 origin, float dps, int gridRes, hipStream_t stream,
-						   SvoBuildResult* out );
+// flags: 1 = no DAG de-duplication (every sibling group is a node), 2 = never embed masks in child pointers
+int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const float* emisHost, uint64_t nVertices, f3 origin, float dps, int gridRes, int flags,
+						   hipStream_t stream, SvoBuildResult* out );
+int svoBuildSynthetic( uint64_t nRandomVoxels, uint64_t seed, int gridRes, int flags, hipStream_t stream, SvoBuildResult* out );

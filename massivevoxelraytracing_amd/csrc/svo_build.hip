@@ -590,6 +590,97 @@ __global__ void __launch_bounds__( BB ) kEmbedMasks( Node64* __restrict__ nodes,
 	nodes[node].children[k] = child | (uint32_t)masks[child] << 24;
 }
 
+// ---- no-DAG path: every sibling group becomes a node, written straight to its final slot (group index = node index
+// within the level; the reference's ENABLE_GPU_DAG-off branch, voxKernel.cu:322-334, numbers them with a racing
+// atomicInc -- here the numbering is the deterministic group order) ------------------------------------------------------
+__global__ void __launch_bounds__( BB ) kMakeNodesDirect( const Task* __restrict__ tasks, uint64_t n, const uint32_t* __restrict__ blockOff, uint32_t nodeBase,
+														   Node64* __restrict__ nodes, uint8_t* __restrict__ masks, Task* __restrict__ tasksOut )
+{
+	__shared__ uint32_t wc[BB / WAVE];
+	const uint64_t nBlocks = ( n + BB - 1 ) / BB;
+	for( uint64_t vb = blockIdx.x; vb < nBlocks; vb += gridDim.x )
+	{
+		uint64_t i = vb * BB + threadIdx.x;
+		bool head = i < n ? ( i == 0 || ( tasks[i - 1].morton >> 3 ) != ( tasks[i].morton >> 3 ) ) : false;
+		uint32_t r = rankInBlock( head, wc );
+		if( head )
+		{
+			Node64 nd;
+			for( int j = 0; j < 8; j++ )
+			{
+				nd.children[j] = MVRT_LEAF;
+				nd.psum[j] = 0;
+			}
+			uint32_t mask = 0;
+			const uint64_t parent = tasks[i].morton >> 3;
+			for( uint64_t j = i; j < n && ( tasks[j].morton >> 3 ) == parent; j++ )
+			{
+				Task t = tasks[j];
+				uint32_t space = (uint32_t)( t.morton & 7 );
+				mask |= 1u << space;
+				nd.children[space] = t.child;
+				nd.psum[space] = t.count;
+			}
+			uint32_t run = 0;
+			for( int j = 0; j < 8; j++ )
+			{
+				uint32_t v = nd.psum[j];
+				nd.psum[j] = run;
+				run += v;
+			}
+			const uint32_t g = blockOff[vb] + r;
+			const uint64_t idx = (uint64_t)nodeBase + g;
+			nodes[idx] = nd;
+			masks[idx] = (uint8_t)mask;
+			Task o;
+			o.morton = parent;
+			o.child = (uint32_t)idx;
+			o.count = run;
+			tasksOut[g] = o;
+		}
+	}
+}
+// non-embedded flavour: the node's own mask goes into its psum[0] slot (always 0), see traverse_stream.h
+__global__ void __launch_bounds__( BB ) kMaskIntoPsum0( Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint64_t nNodes )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < nNodes; i += (uint64_t)gridDim.x * BB ) nodes[i].psum[0] = masks[i];
+}
+// distinct parents per level for ALL levels in one pass (the reference's octreeTaskInit counters, voxKernel.cu:257-265)
+__global__ void __launch_bounds__( BB ) kLevelCounts( const uint64_t* __restrict__ morton, uint64_t n, int levels, unsigned long long* __restrict__ counts )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BB )
+	{
+		const uint64_t a = morton[i], b = i ? morton[i - 1] : 0;
+		for( int l = 0; l < levels; l++ )
+		{
+			const bool head = i == 0 || ( a >> ( 3 * ( l + 1 ) ) ) != ( b >> ( 3 * ( l + 1 ) ) );
+			const unsigned long long m = __ballot( head );
+			if( head && ( threadIdx.x & 63 ) == (uint32_t)__builtin_ctzll( m ) ) atomicAdd( &counts[l], (unsigned long long)__popcll( m ) );
+		}
+	}
+}
+// seeded synthetic voxels: uniformly random cells of the grid with hash-derived colours; ~1/256 of them emissive
+MVRT_HDI uint64_t splitmix64( uint64_t x )
+{
+	x += 0x9E3779B97F4A7C15ull;
+	x = ( x ^ ( x >> 30 ) ) * 0xBF58476D1CE4E5B9ull;
+	x = ( x ^ ( x >> 27 ) ) * 0x94D049BB133111EBull;
+	return x ^ ( x >> 31 );
+}
+__global__ void __launch_bounds__( BB ) kSyntheticVoxels( uint64_t n, uint64_t seed, uint32_t gridRes, uint64_t* __restrict__ mortonOut, uint64_t* __restrict__ attrOut )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BB )
+	{
+		const uint64_t h = splitmix64( seed + i );
+		const uint64_t c = splitmix64( h );
+		const uint32_t x = (uint32_t)( h ) & ( gridRes - 1 ), y = (uint32_t)( h >> 21 ) & ( gridRes - 1 ), z = (uint32_t)( h >> 42 ) & ( gridRes - 1 );
+		mortonOut[i] = mortonEncode( x, y, z );
+		const uint64_t rgb = ( ( c & 0xFFFFFFull ) | 0x404040ull ); // keep reflectance above 0.25
+		const uint64_t emissive = ( ( c >> 56 ) == 0 ) ? rgb : 0ull;
+		attrOut[i] = rgb | 255ull << 24 | emissive << 32 | 255ull << 56;
+	}
+}
+
 struct MaxOp
 {
 	__host__ __device__ uint32_t operator()( uint32_t a, uint32_t b ) const { return a > b ? a : b; }
@@ -603,7 +694,10 @@ int gridFor( uint64_t n )
 }
 } // namespace
 
-int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const float* emisHost, uint64_t nVertices, f3 origin, float dps, int gridRes, hipStream_t st,
+static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalDumped, int gridRes, int flags, hipStream_t st, unsigned long long* counter, uint32_t* hasEmission,
+							   uint32_t* scalarOut, SvoBuildResult* out );
+
+int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const float* emisHost, uint64_t nVertices, f3 origin, float dps, int gridRes, int flags, hipStream_t st,
 						   SvoBuildResult* out )
 {
 	const uint32_t nTri = (uint32_t)( nVertices / 3 );
@@ -645,12 +739,42 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 		mvrtSetError( "mvrt_svo_build: %llu voxel fragments exceed the 32-bit index range of this builder", totalDumped );
 		return 1;
 	}
-	Buf keysA, valsA, keysB, valsB;
-	if( keysA.alloc( totalDumped * 8 ) || valsA.alloc( totalDumped * 8 ) || keysB.alloc( totalDumped * 8 ) || valsB.alloc( totalDumped * 8 ) ) return 1;
+	Buf keysA, valsA;
+	if( keysA.alloc( totalDumped * 8 ) || valsA.alloc( totalDumped * 8 ) ) return 1;
 	MVRT_HIP( hipMemsetAsync( counter, 0, 8, st ) );
 	hipLaunchKernelGGL( kVoxelize<true>, dim3( triGrid ), dim3( 128 ), 0, st, dVerts.as<float>(), dCols.as<float>(), dEmis.as<float>(), nTri, counter, origin, dps, gridRes,
 						keysA.as<uint64_t>(), valsA.as<uint64_t>() );
 
+	dVerts.release();
+	dCols.release();
+	dEmis.release();
+	return buildFromFragments( keysA, valsA, totalDumped, gridRes, flags, st, counter, hasEmission, scalarOut, out );
+}
+
+int svoBuildSynthetic( uint64_t nRandomVoxels, uint64_t seed, int gridRes, int flags, hipStream_t st, SvoBuildResult* out )
+{
+	if( nRandomVoxels == 0 || nRandomVoxels >= 0xFFFFFFFFull )
+	{
+		mvrtSetError( "mvrt_svo_build_synthetic: voxel count must be in [1, 2^32-2]" );
+		return 1;
+	}
+	Buf dCounter, keysA, valsA;
+	if( dCounter.alloc( 64 ) || keysA.alloc( nRandomVoxels * 8 ) || valsA.alloc( nRandomVoxels * 8 ) ) return 1;
+	MVRT_HIP( hipMemsetAsync( dCounter.p, 0, 64, st ) );
+	unsigned long long* counter = dCounter.as<unsigned long long>();
+	hipLaunchKernelGGL( kSyntheticVoxels, dim3( gridFor( nRandomVoxels ) ), dim3( BB ), 0, st, nRandomVoxels, seed, (uint32_t)gridRes, keysA.as<uint64_t>(), valsA.as<uint64_t>() );
+	return buildFromFragments( keysA, valsA, nRandomVoxels, gridRes, flags, st, counter, (uint32_t*)( counter + 1 ), (uint32_t*)( counter + 2 ), out );
+}
+
+static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalDumped, int gridRes, int flags, hipStream_t st, unsigned long long* counter, uint32_t* hasEmission,
+							   uint32_t* scalarOut, SvoBuildResult* out )
+{
+	(void)counter;
+	int levels = 0;
+	while( ( 1 << levels ) < gridRes ) levels++;
+	const bool dag = !( flags & 1 );
+	Buf keysB, valsB;
+	if( keysB.alloc( totalDumped * 8 ) || valsB.alloc( totalDumped * 8 ) ) return 1;
 	// ---- sort (IntersectorOctreeGPU.hpp:117-124) ----
 	{
 		size_t tmpBytes = 0;
@@ -708,6 +832,42 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 		MVRT_HIP( hipMemcpyAsync( &nGroups, scalarOut, 4, hipMemcpyDeviceToHost, st ) );
 		MVRT_HIP( hipStreamSynchronize( st ) );
 
+		if( !dag ) // every group is a node: write it straight into the (pre-sized) final arrays
+		{
+			if( level == 0 )
+			{
+				// distinct parents per level in one pass -> exact node count -> one allocation, no concatenation copy
+				Buf dCounts;
+				if( dCounts.alloc( 32 * 8 ) ) return 1;
+				MVRT_HIP( hipMemsetAsync( dCounts.p, 0, 32 * 8, st ) );
+				hipLaunchKernelGGL( kLevelCounts, dim3( gridFor( nVoxels ) ), dim3( BB ), 0, st, morton.as<uint64_t>(), (uint64_t)nVoxels, levels, dCounts.as<unsigned long long>() );
+				unsigned long long hc[32];
+				MVRT_HIP( hipMemcpyAsync( hc, dCounts.p, sizeof( hc ), hipMemcpyDeviceToHost, st ) );
+				MVRT_HIP( hipStreamSynchronize( st ) );
+				unsigned long long total = 0;
+				for( int l = 0; l < levels; l++ ) total += hc[l];
+				if( total >= 0xFFFFFFFEull )
+				{
+					mvrtSetError( "mvrt_svo_build: %llu nodes exceed 32-bit node indices", total );
+					return 1;
+				}
+				Node64* nn = nullptr;
+				uint8_t* mm = nullptr;
+				MVRT_HIP( hipMalloc( (void**)&nn, total * sizeof( Node64 ) ) );
+				MVRT_HIP( hipMalloc( (void**)&mm, total ) );
+				levelNodes.push_back( nn );
+				levelMasks.push_back( mm );
+				levelCount.push_back( (uint32_t)total );
+			}
+			hipLaunchKernelGGL( kMakeNodesDirect, dim3( gridFor( nInput ) ), dim3( BB ), 0, st, cur, (uint64_t)nInput, blockCnt.as<uint32_t>(), nodeBase, levelNodes[0], levelMasks[0], nxt );
+			MVRT_HIP( hipStreamSynchronize( st ) );
+			nodeBase += nGroups;
+			nInput = nGroups;
+			Task* t = cur;
+			cur = nxt;
+			nxt = t;
+			continue;
+		}
 		Buf cands, hashes, groupIds, parents, hashesS, groupS, headPos, headScan, repOf, nodeOfGroup, blockCnt2;
 		if( cands.alloc( (uint64_t)nGroups * sizeof( Cand ) ) || hashes.alloc( (uint64_t)nGroups * 8 ) || groupIds.alloc( (uint64_t)nGroups * 4 ) ||
 			parents.alloc( (uint64_t)nGroups * 8 ) || hashesS.alloc( (uint64_t)nGroups * 8 ) || groupS.alloc( (uint64_t)nGroups * 4 ) ||
@@ -773,11 +933,19 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 	}
 	const uint32_t nNodes = nodeBase;
 	Buf nodes, masks;
-	if( nodes.alloc( (uint64_t)nNodes * sizeof( Node64 ) ) || masks.alloc( nNodes ) )
+	if( !dag )
+	{
+		nodes.p = levelNodes[0]; // written in place, already final
+		masks.p = levelMasks[0];
+		levelNodes.clear();
+		levelMasks.clear();
+	}
+	else if( nodes.alloc( (uint64_t)nNodes * sizeof( Node64 ) ) || masks.alloc( nNodes ) )
 	{
 		freeLevels();
 		return 1;
 	}
+	if( dag )
 	{
 		uint64_t off = 0;
 		for( size_t l = 0; l < levelNodes.size(); l++ )
@@ -789,9 +957,14 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 		MVRT_HIP( hipStreamSynchronize( st ) );
 		freeLevels();
 	}
-	if( nNodes < 0xFFFFFFu )
+	const bool embed = nNodes < 0xFFFFFFu && !( flags & 2 );
+	if( embed )
 	{
 		hipLaunchKernelGGL( kEmbedMasks, dim3( divUp( (uint64_t)nNodes * 8, BB ) ), dim3( BB ), 0, st, nodes.as<Node64>(), masks.as<uint8_t>(), nNodes );
+	}
+	else
+	{
+		hipLaunchKernelGGL( kMaskIntoPsum0, dim3( gridFor( nNodes ) ), dim3( BB ), 0, st, nodes.as<Node64>(), masks.as<uint8_t>(), (uint64_t)nNodes );
 	}
 	uint32_t he = 0;
 	MVRT_HIP( hipMemcpyAsync( &he, hasEmission, 4, hipMemcpyDeviceToHost, st ) );
@@ -805,6 +978,7 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 	out->nNodes = nNodes;
 	out->nVoxels = nVoxels;
 	out->hasEmission = he;
+	out->embedded = embed ? 1 : 0;
 	out->totalDumped = totalDumped;
 	return 0;
 }

@@ -135,7 +135,8 @@ MVRT_DI TraceResult traceRay( const SvoDev& s, f3 ro, f3 rd, bool isShadowRay, u
 				uint32_t child = nd->children[childIndex]; // :381
 				if( !isShadowRay )
 				{
-					skipped += nd->psum[childIndex]; // :388-391
+					// :388-391.  Non-embedded flavour: psum[0] (always 0) holds the node's own mask on the device
+					skipped += ( s.embedded || childIndex ) ? nd->psum[childIndex] : 0u;
 				}
 				if( COUNT_DESCENTS ) res.descents++;
 				if( s.embedded )
@@ -153,7 +154,7 @@ MVRT_DI TraceResult traceRay( const SvoDev& s, f3 ro, f3 rd, bool isShadowRay, u
 				else
 				{
 					node = child;
-					if( child != MVRT_LEAF ) nodeMask = s.masks[child];
+					if( child != MVRT_LEAF ) nodeMask = s.nodes[child].psum[0];
 				}
 				tx1 = x1; // :382-386
 				ty1 = y1;

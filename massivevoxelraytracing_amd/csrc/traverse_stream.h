@@ -1,4 +1,12 @@
-// traverse_stream.h -- persistent-wave octree traversal for gfx950 (embedded-mask octrees).
+// traverse_stream.h -- persistent-wave octree traversal for gfx950.
+//
+// Two node-reference flavours (template parameter EMBED):
+//   EMBED = true  : child pointers carry the child's occupancy mask in bits 24-31 (ENABLE_EMBEDED_MASK,
+//                   voxCommon.hpp:7-9); < 2^24 nodes; node offsets fit 32 bits.
+//   EMBED = false : plain 32-bit child indices (up to 2^32-2 nodes, e.g. the 8192^3 non-DAG stress octree);
+//                   a node's own mask is read from the node when it is entered (voxCommon.hpp:353-356).  On the
+//                   device it lives in the node's psum[0] slot -- an exclusive prefix sum starts with 0, so the
+//                   slot is free -- i.e. in the same 64-byte line as the child pointers fetched next.
 //
 // Same results as traverse.h / the reference's octreeTraverse_EfficientParametric
 // (voxCommon.hpp:231-423): identical slab arithmetic, child order, tie-breaks and hit test.  What is
@@ -52,8 +60,16 @@ MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 	{
 		const uint32_t c = (uint32_t)( path >> ( 3u * ( s.levels - 1u - l ) ) ) & 7u;
 		const Node64* nd = s.nodes + n;
-		v += nd->psum[c];
-		n = nd->children[c] & 0xFFFFFFu;
+		if( s.embedded )
+		{
+			v += nd->psum[c];
+			n = nd->children[c] & 0xFFFFFFu;
+		}
+		else
+		{
+			v += c ? nd->psum[c] : 0u; // psum[0] == 0 by construction; the slot holds the node's mask in this flavour
+			n = nd->children[c];
+		}
 	}
 	return v;
 }
@@ -65,6 +81,7 @@ struct TraceCore
 	const Node64* nodes;
 	float lox, loy, loz, hix, hiy, hiz;
 	uint32_t rootRef; // rootIndex | rootMask << 24 (voxCommon.hpp:306)
+	uint32_t rootIndex, rootMask;
 };
 MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
 {
@@ -73,6 +90,8 @@ MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
 	c.lox = s.lower.x; c.loy = s.lower.y; c.loz = s.lower.z;
 	c.hix = s.upper.x; c.hiy = s.upper.y; c.hiz = s.upper.z;
 	c.rootRef = s.rootIndex | ( s.rootMask << 24 );
+	c.rootIndex = s.rootIndex;
+	c.rootMask = s.rootMask;
 	return c;
 }
 
@@ -99,11 +118,12 @@ MVRT_DI uint32_t bfi( uint32_t mask, uint32_t a, uint32_t b ) // (a & mask) | (b
 // all finite never enter the fast loop (whose v_max3/v_min3 assume NaN-free data); they are traced here, one
 // lane at a time if need be, with the reference's exact operation order and a stack in the HBM spill rows
 // (two 16-byte rows per slot).  They are measure-zero in rendering; cost is irrelevant.
+template <bool EMBED>
 MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1, float t0x, float t0y, float t0z, uint32_t vMask, uint4* __restrict__ mySpill,
 							 uint64_t spillStride, float* resT, int* resN, uint64_t* pathOut, uint32_t* descentsOut )
 {
 	const float dtx = tx1 - t0x, dty = ty1 - t0y, dtz = tz1 - t0z;
-	uint32_t node = s.rootRef, level = 0, childMask = 8u, sp = 0, descents = 0;
+	uint32_t node = EMBED ? s.rootRef : s.rootIndex, nodeMask = s.rootMask, level = 0, childMask = 8u, sp = 0, descents = 0;
 	uint64_t path = 0;
 	for( ;; )
 	{
@@ -137,7 +157,8 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 			const bool hasNext = ( childMask & mv ) == 0;
 			const uint32_t childIndex = childMask ^ vMask;
 			const uint32_t nextMask = childMask | mv;
-			if( ( ( node >> ( 24u + childIndex ) ) & 1u ) && !( u < 0.0f ) )
+			const bool exists = EMBED ? ( ( node >> ( 24u + childIndex ) ) & 1u ) != 0 : ( ( nodeMask >> childIndex ) & 1u ) != 0;
+			if( exists && !( u < 0.0f ) )
 			{
 				if( hasNext )
 				{
@@ -149,12 +170,20 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 					b.x = nextMask | ( level << 3 );
 					b.y = (uint32_t)path;
 					b.z = (uint32_t)( path >> 32 );
-					b.w = 0;
+					b.w = nodeMask;
 					mySpill[(uint64_t)( 2 * sp ) * spillStride] = a;
 					mySpill[(uint64_t)( 2 * sp + 1 ) * spillStride] = b;
 					sp++;
 				}
-				node = s.nodes[node & 0xFFFFFFu].children[childIndex];
+				if( EMBED )
+				{
+					node = s.nodes[node & 0xFFFFFFu].children[childIndex];
+				}
+				else
+				{
+					node = s.nodes[node].children[childIndex];
+					if( node != MVRT_LEAF ) nodeMask = s.nodes[node].psum[0];
+				}
 				descents++;
 				path = ( path << 3 ) | childIndex;
 				tx1 = x1;
@@ -185,6 +214,7 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 			childMask = b.x & 7u;
 			level = ( b.x >> 3 ) & 31u;
 			path = (uint64_t)b.y | ( (uint64_t)b.z << 32 );
+			nodeMask = b.w;
 		}
 	}
 	*pathOut = path;
@@ -199,7 +229,7 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 // (one store site, many lanes per store instruction), then load new rays into them; (2) one traversal step for
 // every active lane: straight-line bit arithmetic (v_bfi / v_bfe selects instead of compare-select chains)
 // followed by three shallow branches: descend (with push), pop, hit.
-template <class IO>
+template <bool EMBED, class IO>
 MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING][64] */,
 						  uint4* __restrict__ spill /* [levels][spillStride] */, uint64_t spillStride, uint64_t spillLane )
 {
@@ -218,7 +248,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 	bool isShadow = false;
 	uint32_t ray = 0;
 	float dtx = 0, dty = 0, dtz = 0, tx1 = 0, ty1 = 0, tz1 = 0;
-	uint32_t vMask = 0, node = 0, level = 0, childMask = 8u, pending = 0, inLds = 0, descents = 0;
+	uint32_t vMask = 0, node = 0, nodeMask = 0, level = 0, childMask = 8u, pending = 0, inLds = 0, descents = 0;
 	uint64_t path = 0;
 	float resT = MVRT_MAXF;
 	int resN = -1;
@@ -308,7 +338,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 								 ( ( mvrt_f2u( tz1 - t0z ) & 0x7F800000u ) == 0x7F800000u ) )
 						{
 							// irregular ray (inf / NaN slab delta): exact reference emulation, see traceIrregular
-							traceIrregular( s, tx1, ty1, tz1, t0x, t0y, t0z, vMask, mySpill, spillStride, &resT, &resN, &path, &descents );
+							traceIrregular<EMBED>( s, tx1, ty1, tz1, t0x, t0y, t0z, vMask, mySpill, spillStride, &resT, &resN, &path, &descents );
 							st = 2u;
 						}
 						else
@@ -316,7 +346,8 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 							dtx = tx1 - t0x;
 							dty = ty1 - t0y;
 							dtz = tz1 - t0z;
-							node = s.rootRef;
+							node = EMBED ? s.rootRef : s.rootIndex;
+							nodeMask = s.rootMask;
 							level = 0;
 							childMask = 8u;
 							pending = 0;
@@ -383,7 +414,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const uint32_t nextMask = cm | mv;								  // :370
 			const bool leaf = node == MVRT_LEAF;							  // :322
 			const bool hasNext = ( cm & mv ) == 0;							  // :368
-			const bool exists = ( ( node >> ( 24u + childIndex ) ) & 1u ) != 0;
+			const bool exists = EMBED ? ( ( node >> ( 24u + childIndex ) ) & 1u ) != 0 : ( ( nodeMask >> childIndex ) & 1u ) != 0;
 			const bool go = !leaf && exists && !( u < 0.0f ); // :373-375
 			const bool hit = leaf && ( 0.0f < S );			  // :324
 			const bool pop = leaf ? !hit : ( !go && !hasNext );
@@ -413,8 +444,16 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					pending |= 1u << level;
 					inLds |= 1u << level;
 				}
-				// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
-				node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
+				if( EMBED )
+				{
+					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
+					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
+				}
+				else
+				{
+					node = nodes[node].children[childIndex];					  // up to 2^32 nodes: 64-bit addressing
+					if( node != MVRT_LEAF ) nodeMask = nodes[node].psum[0]; // the child's own mask, same line as its pointers
+				}
 				descents++;
 				path = ( path << 3 ) | childIndex;
 				tx1 = x1; // :382-386
@@ -443,6 +482,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					path >>= 3u * ( level - L );
 					level = L;
 					node = e.x;
+					if( !EMBED ) nodeMask = nodes[node].psum[0]; // re-read the node's mask (its line was fetched when it was entered)
 					childMask = ( e.y >> 31 ) | ( ( e.z >> 30 ) & 2u ) | ( ( e.w >> 29 ) & 4u );
 					tx1 = mvrt_u2f( e.y & 0x7FFFFFFFu );
 					ty1 = mvrt_u2f( e.z & 0x7FFFFFFFu );

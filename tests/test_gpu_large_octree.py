@@ -1,0 +1,126 @@
+"""The flavour used by the HBM-bound stress configuration (BASELINE.json configs[4]): non-DAG octree, plain 32-bit
+child indices with the node mask fetched from the node (voxCommon.hpp:353-356), seeded synthetic voxels generated and
+built on the GPU.  Checked against the oracle at sizes it handles in seconds; bit-exact as everywhere else."""
+import numpy as np
+import pytest
+
+from common import bunny_tris, hdr_bytes, position_colors, probe_camera
+from test_gpu_parity import assert_hits_equal, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def mv():
+    import massivevoxelraytracing_amd as m
+    m.lib()
+    return m
+
+
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
+    return x ^ (x >> np.uint64(31))
+
+
+def synthetic_reference(O, res, n, seed):
+    """numpy restatement of the documented generator (include/mvrt.h) + the oracle's merge and non-DAG build"""
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)
+        h = splitmix64(np.uint64(seed) + i)
+        c = splitmix64(h)
+    m = np.uint64(res - 1)
+    xyz = np.stack([h & m, (h >> np.uint64(21)) & m, (h >> np.uint64(42)) & m], -1).astype(np.uint32)
+    morton = O.morton_encode_batch(xyz)
+    rgb = (c & np.uint64(0xFFFFFF)) | np.uint64(0x404040)
+    em = np.where((c >> np.uint64(56)) == 0, rgb, np.uint64(0))
+    attrs = np.zeros((n, 8), np.uint8)
+    for k in range(3):
+        attrs[:, k] = ((rgb >> np.uint64(8 * k)) & np.uint64(255)).astype(np.uint8)
+        attrs[:, 4 + k] = ((em >> np.uint64(8 * k)) & np.uint64(255)).astype(np.uint8)
+    attrs[:, 3] = 255
+    attrs[:, 7] = 255
+    return O.merge_voxels(morton, attrs)
+
+
+def test_non_dag_non_embedded_build_and_traversal(mv, O):
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    from massivevoxelraytracing_amd import scenes
+    res = 256
+    origin, dps = scenes.bounding_grid(tris.reshape(-1, 3), res)
+    svo = mv.IntersectorOctreeGPU()
+    svo.build(tris.reshape(-1, 3), cols.reshape(-1, 3), emis.reshape(-1, 3), None, origin, dps, res, flags=svo.BUILD_NO_DAG | svo.BUILD_NO_EMBEDDED_MASK)
+    sc = O.build_scene_from_triangles(tris, res, cols, emis, dag=False, embed=False)
+    info = svo.info()
+    assert info.embeddedMask == 0 and info.numberOfNodes == len(sc.nodes) and info.numberOfVoxels == len(sc.morton)
+    nodes, attrs, morton = svo.download(want_morton=True)
+    got = nodes.view(O.NODE_DTYPE)
+    assert np.array_equal(morton, sc.morton) and np.array_equal(attrs, sc.attrs)
+    for f in ("mask", "children", "psum"):
+        assert np.array_equal(got[f], sc.nodes[f]), f
+    # persistent traversal, non-embedded flavour
+    ro, rd = random_rays(sc, 100_000, 21)
+    sh = (np.arange(len(ro)) % 4 == 0).astype(np.uint8)
+    assert_hits_equal(sc.trace(ro, rd, sh, threads=8, want_descents=True), svo.intersect(ro, rd, sh, want_descents=True))
+    cam = probe_camera(origin, dps, res)
+    want = sc.render_primary(cam, 640, 360, show_vertex_color=True, threads=8)
+    gotr = svo.render(cam, 640, 360, showVertexColor=True)
+    assert np.array_equal(want["rgba"], gotr["rgba"])
+    assert_hits_equal(want, gotr)
+    # DAG and non-DAG octrees give the same hits
+    dag = mv.IntersectorOctreeGPU()
+    dag.build(tris.reshape(-1, 3), cols.reshape(-1, 3), emis.reshape(-1, 3), None, origin, dps, res)
+    assert dag.info().embeddedMask == 1 and dag.info().numberOfNodes < info.numberOfNodes
+    assert_hits_equal(dag.intersect(ro, rd, sh, want_descents=True), svo.intersect(ro, rd, sh, want_descents=True))
+
+
+def test_path_tracer_on_non_embedded_octree(mv, O):
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    sc = O.build_scene_from_triangles(tris, 128, cols, emis, dag=False, embed=False)
+    rgba, hw, hh = O.decode_rgbe(hdr_bytes())
+    w, h = 128, 72
+    cam = probe_camera(sc.origin, sc.dps, 128, focus=9.0, lens_r=0.05)
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    pt.loadHDRIPixels(None, rgba, hw, hh, rgba, hw, hh)
+    pt.m_intersectorOctreeGPU.upload(sc.nodes, sc.attrs, sc.origin, sc.dps, 128, sc.has_emission, embeddedMask=False)
+    for _ in range(2):
+        pt.step(None, cam)
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb = np.zeros((w * h, 4), np.float32)
+    rays = 0
+    for it in range(2):
+        fb, _, cnt = sc.render_pt(H, cam, w, h, it, math_mode=1, fb=fb, threads=8)
+        rays += cnt["rays"]
+    assert np.array_equal(pt.read_framebuffer()[: w * h], fb)
+    assert pt.stats()["rays"] == rays
+
+
+@pytest.mark.parametrize("res,n,flags", [(64, 5000, 3), (256, 200_000, 1), (512, 1_000_000, 3), (128, 300_000, 0)])
+def test_synthetic_octree_matches_documented_generator(mv, O, res, n, flags):
+    svo = mv.IntersectorOctreeGPU()
+    svo.build_synthetic(res, n, seed=1234, flags=flags)
+    morton_w, attrs_w, he = synthetic_reference(O, res, n, 1234)
+    dag, embed = not (flags & 1), not (flags & 2)
+    nodes_w = O.build_octree(morton_w, res, dag=dag, embed=embed)
+    info = svo.info()
+    assert info.totalDumpedVoxels == n and info.numberOfVoxels == len(morton_w) and info.numberOfNodes == len(nodes_w)
+    assert info.hasEmission == he and info.embeddedMask == int(embed)
+    nodes, attrs, morton = svo.download(want_morton=True)
+    got = nodes.view(O.NODE_DTYPE)
+    assert np.array_equal(morton, morton_w) and np.array_equal(attrs, attrs_w)
+    for f in ("mask", "children", "psum"):
+        assert np.array_equal(got[f], nodes_w[f]), f
+    sc = O.Scene(nodes_w, attrs_w, np.zeros(3, np.float32), np.float32(1.0 / res), res, he, embedded=embed)
+    ro, rd = random_rays(sc, 50_000, res)
+    assert_hits_equal(sc.trace(ro, rd, threads=8, want_descents=True), svo.intersect(ro, rd, want_descents=True))
