@@ -33,6 +33,53 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured copy)
 
 
+def stress(args, mv):
+    """BASELINE.json configs[4]: synthetic non-DAG octree far larger than the 256 MB Infinity Cache, incoherent rays;
+    the one configuration where the traversal is bound by HBM (every descent is a dependent 64-byte line fetch)."""
+    svo = mv.IntersectorOctreeGPU()
+    res, n_vox, n_rays = args.grid_res, int(args.voxels), int(args.rays)
+    t0 = time.time()
+    svo.build_synthetic(res, n_vox, seed=2024, flags=svo.BUILD_NO_DAG | svo.BUILD_NO_EMBEDDED_MASK)
+    mv.synchronize()
+    build_s = time.time() - t0
+    info = svo.info()
+    rng = np.random.default_rng(7)
+    # incoherent rays: origins on a sphere around the unit cube, aimed at uniformly random interior points
+    d = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ro = (0.5 + 1.2 * d).astype(np.float32)
+    rd = (rng.random((n_rays, 3), dtype=np.float32) - ro).astype(np.float32)
+    dev = [mv.DeviceArray.from_host(np.ascontiguousarray(a)) for a in (ro[:, 0], ro[:, 1], ro[:, 2], rd[:, 0], rd[:, 1], rd[:, 2])]
+    t = mv.DeviceArray(n_rays, np.float32)
+    nm = mv.DeviceArray(n_rays, np.int32)
+    vi = mv.DeviceArray(n_rays, np.uint32)
+    de = mv.DeviceArray(n_rays, np.uint32)
+    for _ in range(args.warmup):
+        svo.intersect_device(n_rays, *dev, None, t, nm, vi, de)
+    mv.synchronize()
+    tt = time.perf_counter()
+    for _ in range(args.steps):
+        svo.intersect_device(n_rays, *dev, None, t, nm, vi, de)
+    mv.synchronize()
+    el = time.perf_counter() - tt
+    desc = de.to_host().astype(np.uint64)
+    hits = int((t.to_host() != mv.MAX_FLOAT).sum())
+    algo = n_rays * 40 + int(desc.sum()) * 8 + hits * 8
+    line_bytes = int(desc.sum()) * 64  # what a dependent pointer chase really moves: one 64-byte node line per descent
+    gbs = algo * args.steps / el / 1e9
+    print(json.dumps({
+        "metric": "Mrays/sec (incoherent rays, HBM-resident synthetic octree)", "value": round(n_rays * args.steps / el / 1e6, 2), "unit": "Mrays/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic %d^3 non-DAG SVO, %d random voxels, %d incoherent rays per step (trace + vIndex resolve)" % (res, n_vox, n_rays),
+                   "voxels": int(info.numberOfVoxels), "nodes": int(info.numberOfNodes), "node_gb": round(info.numberOfNodes * 64 / 1e9, 2),
+                   "embedded_mask": int(info.embeddedMask), "svo_build_s": round(build_s, 2), "hits": hits, "descents_per_ray": round(float(desc.mean()), 2)},
+        "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<false>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
+                     "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts the 64-byte node line each descent pulls from HBM"},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,7 +92,9 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--mode", default="pt", choices=["pt", "primary"], help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2)")
+    ap.add_argument("--voxels", type=float, default=1e8, help="stress mode: random voxels of the synthetic octree")
+    ap.add_argument("--rays", type=float, default=6.4e7, help="stress mode: incoherent rays per step")
+    ap.add_argument("--mode", default="pt", choices=["pt", "primary", "stress"], help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2)")
     ap.add_argument("--emulate-tiles", type=int, default=0, help="diagnostic: render only tile 0 of N on one GPU (predicts per-rank time of an N-GPU run)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
@@ -76,6 +125,9 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.mode == "stress":
+        return stress(args, mv)
 
     # ---- scene + renderer (outside the timed region) ----
     t_setup = time.time()

@@ -134,11 +134,12 @@ struct mvrt_svo
 {
 	Node64* nodes = nullptr;
 	uint8_t* masks = nullptr;
+	uint32_t* psumCold = nullptr; // non-embedded flavour only
 	uint2* attrs = nullptr;
 	uint64_t* morton = nullptr; // only after build()
 	mutable DevBuf wsBuf;		// traversal workspace (spill rows + cursor), sized on demand
 	mutable DevBuf pathBuf;
-	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0 };
+	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
 	mvrt_svo_info info;
 	uint8_t rootMask = 0;
 	mvrt_svo()
@@ -150,10 +151,12 @@ struct mvrt_svo
 	{
 		if( nodes ) (void)hipFree( nodes );
 		if( masks ) (void)hipFree( masks );
+		if( psumCold ) (void)hipFree( psumCold );
 		if( attrs ) (void)hipFree( attrs );
 		if( morton ) (void)hipFree( morton );
 		nodes = nullptr;
 		masks = nullptr;
+		psumCold = nullptr;
 		attrs = nullptr;
 		morton = nullptr;
 		float es = info.emissionScale;
@@ -170,7 +173,7 @@ struct mvrt_svo
 		}
 		const uint64_t lanes = traceWorkspaceLanes();
 		const uint64_t rows = 2 * (uint64_t)( info.levels ? info.levels : 1 ) + 2; // fast path: 1 row per level; irregular rays: 2 per slot
-		const uint64_t bytes = 256 + rows * lanes * sizeof( uint4 );
+		const uint64_t bytes = 256 + rows * lanes * ( sizeof( uint4 ) + sizeof( uint32_t ) );
 		if( wsBuf.bytes < bytes )
 		{
 			if( wsBuf.alloc( bytes ) ) return 1;
@@ -178,6 +181,7 @@ struct mvrt_svo
 		ws.cursor = (unsigned long long*)wsBuf.p;
 		ws.spill = (uint4*)( (uint8_t*)wsBuf.p + 256 );
 		ws.spillStride = lanes;
+		ws.spillMask = (uint32_t*)( ws.spill + rows * lanes );
 		return 0;
 	}
 	SvoDev dev() const
@@ -185,6 +189,7 @@ struct mvrt_svo
 		SvoDev d;
 		d.nodes = nodes;
 		d.masks = masks;
+		d.psumCold = psumCold;
 		d.attrs = attrs;
 		d.nNodes = info.numberOfNodes;
 		d.nVoxels = info.numberOfVoxels;
@@ -250,7 +255,8 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	MVRT_HIP( hipMalloc( (void**)&svo->masks, numberOfNodes ) );
 	MVRT_HIP( hipMalloc( (void**)&svo->attrs, (uint64_t)( numberOfVoxels ? numberOfVoxels : 1 ) * 8 ) );
 	if( numberOfVoxels ) MVRT_HIP( hipMemcpyAsync( svo->attrs, attribs8Host, (uint64_t)numberOfVoxels * 8, hipMemcpyHostToDevice, st ) );
-	if( launchConvertNodes( raw.as<uint8_t>(), numberOfNodes, svo->nodes, svo->masks, embeddedMask ? 0 : 1, st ) ) return 1;
+	if( !embeddedMask ) MVRT_HIP( hipMalloc( (void**)&svo->psumCold, (uint64_t)numberOfNodes * 32 ) );
+	if( launchConvertNodes( raw.as<uint8_t>(), numberOfNodes, svo->nodes, svo->masks, svo->psumCold, embeddedMask ? 0 : 1, st ) ) return 1;
 	svo->info.numberOfNodes = numberOfNodes;
 	svo->info.numberOfVoxels = numberOfVoxels;
 	svo->info.hasEmission = hasEmission ? 1 : 0;
@@ -266,6 +272,7 @@ static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origi
 {
 	svo->nodes = r.nodes;
 	svo->masks = r.masks;
+	svo->psumCold = r.psumCold;
 	svo->attrs = r.attrs;
 	svo->morton = r.morton;
 	svo->info.numberOfNodes = r.nNodes;
@@ -325,7 +332,7 @@ MVRT_EXPORT int mvrt_svo_download( const mvrt_svo* svo, void* nodes68Host, void*
 	{
 		DevBuf raw;
 		if( raw.alloc( (uint64_t)svo->info.numberOfNodes * 68 ) ) return 1;
-		if( launchNodesTo68( svo->nodes, svo->masks, svo->info.numberOfNodes, raw.as<uint8_t>(), svo->info.embeddedMask ? 0 : 1, st ) ) return 1;
+		if( launchNodesTo68( svo->nodes, svo->masks, svo->psumCold, svo->info.numberOfNodes, raw.as<uint8_t>(), svo->info.embeddedMask ? 0 : 1, st ) ) return 1;
 		MVRT_HIP( hipMemcpyAsync( nodes68Host, raw.p, raw.bytes, hipMemcpyDeviceToHost, st ) );
 		MVRT_HIP( hipStreamSynchronize( st ) );
 	}
@@ -644,7 +651,7 @@ struct mvrt_pt
 	{
 		DevBuf work, wsBuf;
 		PtBuffers buf;
-		TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0 };
+		TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
 		hipStream_t stream = nullptr;
 		hipEvent_t accumDone = nullptr;
 	};
@@ -834,7 +841,7 @@ static int allocWork( mvrt_pt* pt )
 		{
 			sl.work.release();
 			sl.wsBuf.release();
-			sl.ws = TraceWorkspace{ nullptr, 0, nullptr, nullptr, 0 };
+			sl.ws = TraceWorkspace{ nullptr, 0, nullptr, nullptr, 0, nullptr };
 			memset( &sl.buf, 0, sizeof( sl.buf ) );
 			continue;
 		}
@@ -850,7 +857,7 @@ static int ensureSlotWorkspace( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
 	const uint64_t lanes = traceWorkspaceLanes();
 	const uint64_t rows = 2 * (uint64_t)( pt->intersector->info.levels ? pt->intersector->info.levels : 1 ) + 2;
-	const uint64_t bytes = 256 + rows * lanes * sizeof( uint4 );
+	const uint64_t bytes = 256 + rows * lanes * ( sizeof( uint4 ) + sizeof( uint32_t ) );
 	if( sl.wsBuf.bytes < bytes )
 	{
 		if( sl.wsBuf.alloc( bytes ) ) return 1;
@@ -858,6 +865,7 @@ static int ensureSlotWorkspace( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	sl.ws.cursor = (unsigned long long*)sl.wsBuf.p;
 	sl.ws.spill = (uint4*)( (uint8_t*)sl.wsBuf.p + 256 );
 	sl.ws.spillStride = lanes;
+	sl.ws.spillMask = (uint32_t*)( sl.ws.spill + rows * lanes );
 	return 0;
 }
 

@@ -74,7 +74,8 @@ template <bool EMBED>
 __global__ void __launch_bounds__( 64 ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	traceStream<EMBED>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
+	traceStream<EMBED>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask, ws.spillMask );
 }
 
 struct PrimaryIO
@@ -122,7 +123,9 @@ template <bool EMBED>
 __global__ void __launch_bounds__( 64 ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	traceStream<EMBED>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
+	traceStream<EMBED>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
+						ws.spillMask );
 }
 
 static uint32_t streamChunk( uint64_t total, uint64_t waves )
@@ -636,6 +639,7 @@ template <bool EMBED>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
+	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
 	PtIO io;
 	io.table = P.buf.selfDev;
 	io.setIdx = setIdx;
@@ -664,7 +668,8 @@ __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtPara
 	c = ( c + 63 ) / 64 * 64;
 	if( c < 64 ) c = 64;
 	if( c > chunk ) c = chunk;
-	traceStream<EMBED>( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x );
+	traceStream<EMBED>( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
+						ws.spillMask );
 	unsigned long long dN = waveSum( (unsigned long long)io.dNormal ), dS = waveSum( (unsigned long long)io.dShadow ), nH = waveSum( (unsigned long long)io.nHits );
 #ifdef MVRT_UTIL_STATS
 	if( threadIdx.x == 0 )

@@ -3,7 +3,8 @@
 #include "launch.h"
 
 // ---- reference 68-byte AoS nodes <-> one 64-byte line per node -----------------------------------------
-__global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restrict__ nodes68, uint32_t nNodes, Node64* __restrict__ out, uint8_t* __restrict__ masks, int maskInPsum0 )
+__global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restrict__ nodes68, uint32_t nNodes, Node64* __restrict__ out, uint8_t* __restrict__ masks,
+														 uint32_t* __restrict__ psumCold, int nonEmbedded )
 {
 	// one thread per (node, dword): 16 payload dwords per node
 	uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -11,19 +12,56 @@ __global__ void __launch_bounds__( 256 ) kConvertNodes( const uint8_t* __restric
 	uint32_t w = gid % 16;
 	if( node >= nNodes ) return;
 	const uint32_t* src = (const uint32_t*)( nodes68 + node * 68 ); // 68 is a multiple of 4: aligned dwords
-	uint32_t v = src[1 + w];
-	if( maskInPsum0 && w == 8 ) v = src[0] & 0xFF; // psum[0] (== 0) carries the node's own mask in the non-embedded flavour
-	( (uint32_t*)( out + node ) )[w] = v;
+	const uint32_t v = src[1 + w];
+	if( nonEmbedded && w >= 8 ) psumCold[node * 8 + ( w - 8 )] = v; // the hot line keeps child masks instead (kFillChildMasks)
+	else ( (uint32_t*)( out + node ) )[w] = v;
 	if( w == 0 ) masks[node] = (uint8_t)( src[0] & 0xFF );
 }
-int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, int maskInPsum0, hipStream_t stream )
+// non-embedded flavour: the 8 child masks of every node, one byte each, into psum[0..1] of its line
+__global__ void __launch_bounds__( 256 ) kFillChildMasks( Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint64_t nNodes )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nNodes; i += (uint64_t)gridDim.x * 256 )
+	{
+		uint32_t lo = 0, hi = 0;
+		for( int k = 0; k < 8; k++ )
+		{
+			const uint32_t c = nodes[i].children[k];
+			const uint32_t m = c == MVRT_LEAF ? 0u : (uint32_t)masks[c];
+			if( k < 4 ) lo |= m << ( 8 * k );
+			else hi |= m << ( 8 * ( k - 4 ) );
+		}
+		nodes[i].psum[0] = lo;
+		nodes[i].psum[1] = hi;
+	}
+}
+__global__ void __launch_bounds__( 256 ) kMovePsumCold( const Node64* __restrict__ nodes, uint32_t* __restrict__ psumCold, uint64_t nNodes )
+{
+	for( uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < nNodes * 8; g += (uint64_t)gridDim.x * 256 ) psumCold[g] = nodes[g / 8].psum[g % 8];
+}
+static uint32_t cappedGrid( uint64_t n )
+{
+	uint64_t b = ( n + 255 ) / 256;
+	if( b < 1 ) b = 1;
+	return (uint32_t)( b > 65536 ? 65536 : b );
+}
+int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, uint32_t* psumCold, int nonEmbedded, hipStream_t stream )
 {
 	if( nNodes == 0 ) return 0;
-	hipLaunchKernelGGL( kConvertNodes, dim3( divUp( (uint64_t)nNodes * 16, 256 ) ), dim3( 256 ), 0, stream, nodes68, nNodes, out, masks, maskInPsum0 );
+	hipLaunchKernelGGL( kConvertNodes, dim3( divUp( (uint64_t)nNodes * 16, 256 ) ), dim3( 256 ), 0, stream, nodes68, nNodes, out, masks, psumCold, nonEmbedded );
+	if( nonEmbedded ) hipLaunchKernelGGL( kFillChildMasks, dim3( cappedGrid( nNodes ) ), dim3( 256 ), 0, stream, out, masks, (uint64_t)nNodes );
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
-__global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint32_t nNodes, uint8_t* __restrict__ nodes68, int maskInPsum0 )
+int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, uint64_t nNodes, hipStream_t stream )
+{
+	if( nNodes == 0 ) return 0;
+	hipLaunchKernelGGL( kMovePsumCold, dim3( cappedGrid( nNodes * 8 ) ), dim3( 256 ), 0, stream, nodes, psumCold, nNodes );
+	hipLaunchKernelGGL( kFillChildMasks, dim3( cappedGrid( nNodes ) ), dim3( 256 ), 0, stream, nodes, masks, nNodes );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+__global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ psumCold, uint32_t nNodes,
+													  uint8_t* __restrict__ nodes68, int nonEmbedded )
 {
 	uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	uint64_t node = gid / 17;
@@ -31,13 +69,13 @@ __global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ 
 	if( node >= nNodes ) return;
 	uint32_t* dst = (uint32_t*)( nodes68 + node * 68 );
 	uint32_t v = w == 0 ? (uint32_t)masks[node] : ( (const uint32_t*)( nodes + node ) )[w - 1];
-	if( maskInPsum0 && w == 9 ) v = 0; // reference layout: nVoxelsPSum[0] == 0
+	if( nonEmbedded && w >= 9 ) v = psumCold[node * 8 + ( w - 9 )];
 	dst[w] = v;
 }
-int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, int maskInPsum0, hipStream_t stream )
+int launchNodesTo68( const Node64* nodes, const uint8_t* masks, const uint32_t* psumCold, uint32_t nNodes, uint8_t* nodes68, int nonEmbedded, hipStream_t stream )
 {
 	if( nNodes == 0 ) return 0;
-	hipLaunchKernelGGL( kNodesTo68, dim3( divUp( (uint64_t)nNodes * 17, 256 ) ), dim3( 256 ), 0, stream, nodes, masks, nNodes, nodes68, maskInPsum0 );
+	hipLaunchKernelGGL( kNodesTo68, dim3( divUp( (uint64_t)nNodes * 17, 256 ) ), dim3( 256 ), 0, stream, nodes, masks, psumCold, nNodes, nodes68, nonEmbedded );
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }

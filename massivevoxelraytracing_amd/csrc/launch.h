@@ -55,6 +55,7 @@ struct TraceWorkspace
 	unsigned long long* cursor;
 	uint64_t* paths; // per-ray voxel paths of batch / primary-cast launches, resolved to vIndex by a dense pass
 	uint64_t pathCap;
+	uint32_t* spillMask; // non-embedded flavour: node masks of evicted stack entries, [level][lane]
 };
 uint64_t traceWorkspaceLanes();
 
@@ -82,8 +83,10 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 
 int launchResolve( const float4* fb, uint64_t n, uchar4* out, hipStream_t stream );
 int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStridePixels, int W, int H, float4* frame, hipStream_t stream );
-int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, int maskInPsum0, hipStream_t stream );
-int launchNodesTo68( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint8_t* nodes68, int maskInPsum0, hipStream_t stream );
+// nonEmbedded != 0: psum goes to psumCold (nNodes * 8 u32) and the 8 child masks into Node64::psum[0..1]
+int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, uint32_t* psumCold, int nonEmbedded, hipStream_t stream );
+int launchNodesTo68( const Node64* nodes, const uint8_t* masks, const uint32_t* psumCold, uint32_t nNodes, uint8_t* nodes68, int nonEmbedded, hipStream_t stream );
+int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, uint64_t nNodes, hipStream_t stream ); // in place, after a build
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 
 // GPU SVO construction (svo_build.hip)
@@ -91,6 +94,7 @@ struct SvoBuildResult
 {
 	Node64* nodes;
 	uint8_t* masks;
+	uint32_t* psumCold; // non-embedded flavour only
 	uint2* attrs;
 	uint64_t* morton; // kept for parity checks (sorted unique codes)
 	uint32_t nNodes, nVoxels, hasEmission, embedded;

@@ -153,12 +153,14 @@ MVRT_HDI void cameraShootThinLens( const CameraPinhole& c, f3* ro, f3* rd, int x
 struct alignas( 64 ) Node64
 {
 	uint32_t children[8];
-	uint32_t psum[8];
+	uint32_t psum[8]; // embedded flavour: nVoxelsPSum.  Non-embedded flavour: psum[0..1] = the 8 CHILD masks (one byte each),
+					  // so a descent reads pointer and mask of the child from ONE line; nVoxelsPSum then lives in SvoDev::psumCold
 };
 struct SvoDev
 {
 	const Node64* nodes;
 	const uint8_t* masks; // per-node own mask (used for the root and by the non-embedded variant)
+	const uint32_t* psumCold; // non-embedded flavour only: nVoxelsPSum[node * 8 + child] (read by voxelIndexFromPath only)
 	const uint2* attrs;	  // {color rgba8, emission rgba8}
 	uint32_t nNodes, nVoxels;
 	f3 lower, upper;

@@ -640,11 +640,6 @@ __global__ void __launch_bounds__( BB ) kMakeNodesDirect( const Task* __restrict
 		}
 	}
 }
-// non-embedded flavour: the node's own mask goes into its psum[0] slot (always 0), see traverse_stream.h
-__global__ void __launch_bounds__( BB ) kMaskIntoPsum0( Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint64_t nNodes )
-{
-	for( uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < nNodes; i += (uint64_t)gridDim.x * BB ) nodes[i].psum[0] = masks[i];
-}
 // distinct parents per level for ALL levels in one pass (the reference's octreeTaskInit counters, voxKernel.cu:257-265)
 __global__ void __launch_bounds__( BB ) kLevelCounts( const uint64_t* __restrict__ morton, uint64_t n, int levels, unsigned long long* __restrict__ counts )
 {
@@ -962,9 +957,11 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 	{
 		hipLaunchKernelGGL( kEmbedMasks, dim3( divUp( (uint64_t)nNodes * 8, BB ) ), dim3( BB ), 0, st, nodes.as<Node64>(), masks.as<uint8_t>(), nNodes );
 	}
-	else
+	Buf psumCold;
+	if( !embed ) // non-embedded flavour: nVoxelsPSum -> cold array, child masks -> the hot line (traverse_stream.h)
 	{
-		hipLaunchKernelGGL( kMaskIntoPsum0, dim3( gridFor( nNodes ) ), dim3( BB ), 0, st, nodes.as<Node64>(), masks.as<uint8_t>(), (uint64_t)nNodes );
+		if( psumCold.alloc( (uint64_t)nNodes * 32 ) ) return 1;
+		if( launchSplitPsum( nodes.as<Node64>(), masks.as<uint8_t>(), psumCold.as<uint32_t>(), nNodes, st ) ) return 1;
 	}
 	uint32_t he = 0;
 	MVRT_HIP( hipMemcpyAsync( &he, hasEmission, 4, hipMemcpyDeviceToHost, st ) );
@@ -973,6 +970,7 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 
 	out->nodes = (Node64*)nodes.detach();
 	out->masks = (uint8_t*)masks.detach();
+	out->psumCold = (uint32_t*)psumCold.detach();
 	out->attrs = (uint2*)attrs.detach();
 	out->morton = (uint64_t*)morton.detach();
 	out->nNodes = nNodes;

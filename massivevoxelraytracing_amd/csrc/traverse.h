@@ -135,8 +135,7 @@ MVRT_DI TraceResult traceRay( const SvoDev& s, f3 ro, f3 rd, bool isShadowRay, u
 				uint32_t child = nd->children[childIndex]; // :381
 				if( !isShadowRay )
 				{
-					// :388-391.  Non-embedded flavour: psum[0] (always 0) holds the node's own mask on the device
-					skipped += ( s.embedded || childIndex ) ? nd->psum[childIndex] : 0u;
+					skipped += s.embedded ? nd->psum[childIndex] : s.psumCold[(uint64_t)node * 8 + childIndex]; // :388-391
 				}
 				if( COUNT_DESCENTS ) res.descents++;
 				if( s.embedded )
@@ -154,7 +153,7 @@ MVRT_DI TraceResult traceRay( const SvoDev& s, f3 ro, f3 rd, bool isShadowRay, u
 				else
 				{
 					node = child;
-					if( child != MVRT_LEAF ) nodeMask = s.nodes[child].psum[0];
+					nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu; // child masks sit in the parent's line
 				}
 				tx1 = x1; // :382-386
 				ty1 = y1;

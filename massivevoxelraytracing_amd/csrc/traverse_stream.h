@@ -3,10 +3,12 @@
 // Two node-reference flavours (template parameter EMBED):
 //   EMBED = true  : child pointers carry the child's occupancy mask in bits 24-31 (ENABLE_EMBEDED_MASK,
 //                   voxCommon.hpp:7-9); < 2^24 nodes; node offsets fit 32 bits.
-//   EMBED = false : plain 32-bit child indices (up to 2^32-2 nodes, e.g. the 8192^3 non-DAG stress octree);
-//                   a node's own mask is read from the node when it is entered (voxCommon.hpp:353-356).  On the
-//                   device it lives in the node's psum[0] slot -- an exclusive prefix sum starts with 0, so the
-//                   slot is free -- i.e. in the same 64-byte line as the child pointers fetched next.
+//   EMBED = false : plain 32-bit child indices (up to 2^32-2 nodes, e.g. the 8192^3 non-DAG stress octree).  The
+//                   reference reads a node's mask from the node when it is entered (voxCommon.hpp:353-356), i.e. two
+//                   dependent misses per descent on an HBM-resident tree.  Here the 8 child masks sit in the parent's
+//                   64-byte line next to the 8 child pointers (nVoxelsPSum moves to a cold array that only
+//                   voxelIndexFromPath reads), so a descent is ONE line fetch, exactly like the embedded flavour; the
+//                   node mask travels in a fifth stack dword.
 //
 // Same results as traverse.h / the reference's octreeTraverse_EfficientParametric
 // (voxCommon.hpp:231-423): identical slab arithmetic, child order, tie-breaks and hit test.  What is
@@ -67,7 +69,7 @@ MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 		}
 		else
 		{
-			v += c ? nd->psum[c] : 0u; // psum[0] == 0 by construction; the slot holds the node's mask in this flavour
+			v += s.psumCold[(uint64_t)n * 8 + c];
 			n = nd->children[c];
 		}
 	}
@@ -181,8 +183,9 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 				}
 				else
 				{
-					node = s.nodes[node].children[childIndex];
-					if( node != MVRT_LEAF ) nodeMask = s.nodes[node].psum[0];
+					const Node64* nd = s.nodes + node;
+					nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu; // the child's mask, same line
+					node = nd->children[childIndex];
 				}
 				descents++;
 				path = ( path << 3 ) | childIndex;
@@ -231,13 +234,16 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 // followed by three shallow branches: descend (with push), pop, hit.
 template <bool EMBED, class IO>
 MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING][64] */,
-						  uint4* __restrict__ spill /* [levels][spillStride] */, uint64_t spillStride, uint64_t spillLane )
+						  uint4* __restrict__ spill /* [levels][spillStride] */, uint64_t spillStride, uint64_t spillLane, uint32_t* __restrict__ ldsMask = nullptr /* [MVRT_RING][64], !EMBED */,
+						  uint32_t* __restrict__ spillMask = nullptr /* [levels][spillStride], !EMBED */ )
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = (uint32_t)total64;
 	const Node64* __restrict__ nodes = s.nodes;
 	uint4* const myRing = ldsRing + lane;	  // slot k at myRing[k * 64]
 	uint4* const mySpill = spill + spillLane; // level L at mySpill[L * spillStride]
+	uint32_t* const myRingMask = EMBED ? nullptr : ldsMask + lane;
+	uint32_t* const mySpillMask = EMBED ? nullptr : spillMask + spillLane;
 
 	// wave-uniform cursor state
 	uint32_t chunkNext = 0, chunkEnd = 0;
@@ -431,6 +437,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					{
 						const uint32_t lc = __builtin_ctz( clash );
 						mySpill[(uint64_t)lc * spillStride] = myRing[slot * 64];
+						if( !EMBED ) mySpillMask[(uint64_t)lc * spillStride] = myRingMask[slot * 64];
 						inLds &= ~clash;
 					}
 					uint4 e;
@@ -441,6 +448,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					e.z = mvrt_f2u( ty1 ) | ( ( nextMask & 2u ) << 30 );
 					e.w = mvrt_f2u( tz1 ) | ( ( nextMask & 4u ) << 29 );
 					myRing[slot * 64] = e;
+					if( !EMBED ) myRingMask[slot * 64] = nodeMask;
 					pending |= 1u << level;
 					inLds |= 1u << level;
 				}
@@ -451,8 +459,9 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				}
 				else
 				{
-					node = nodes[node].children[childIndex];					  // up to 2^32 nodes: 64-bit addressing
-					if( node != MVRT_LEAF ) nodeMask = nodes[node].psum[0]; // the child's own mask, same line as its pointers
+					const Node64* nd = nodes + node; // up to 2^32 nodes: 64-bit addressing
+					nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu; // the child's mask: same line as
+					node = nd->children[childIndex];												 // its pointer
 				}
 				descents++;
 				path = ( path << 3 ) | childIndex;
@@ -473,16 +482,17 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					const uint32_t L = 31u - __builtin_clz( pending );
 					const uint32_t bit = 1u << L;
 					uint4 e = myRing[( L & ( MVRT_RING - 1 ) ) * 64]; // speculative LDS read (valid iff inLds & bit)
+					if( !EMBED ) nodeMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
 					if( !( inLds & bit ) )
 					{
 						e = mySpill[(uint64_t)L * spillStride];
+						if( !EMBED ) nodeMask = mySpillMask[(uint64_t)L * spillStride];
 					}
 					pending &= ~bit;
 					inLds &= ~bit;
 					path >>= 3u * ( level - L );
 					level = L;
 					node = e.x;
-					if( !EMBED ) nodeMask = nodes[node].psum[0]; // re-read the node's mask (its line was fetched when it was entered)
 					childMask = ( e.y >> 31 ) | ( ( e.z >> 30 ) & 2u ) | ( ( e.w >> 29 ) & 4u );
 					tx1 = mvrt_u2f( e.y & 0x7FFFFFFFu );
 					ty1 = mvrt_u2f( e.z & 0x7FFFFFFFu );
