@@ -146,7 +146,14 @@ static int streamGrid( uint64_t total, int nCUs )
 	if( need < 1 ) need = 1;
 	return (int)( need < cap ? need : cap );
 }
-uint64_t traceWorkspaceLanes() { return (uint64_t)numCUs() * STREAM_WAVES_PER_CU * 64; }
+// lane capacity of a traversal workspace = row stride of the spill rows; rounded up to a power of two so that the kernel
+// addresses row L of a lane with one shift-add on a 32-bit offset (traverse_stream.h)
+uint64_t traceWorkspaceLanes()
+{
+	uint64_t lanes = (uint64_t)numCUs() * STREAM_WAVES_PER_CU * 64, p = 64;
+	while( p < lanes ) p <<= 1;
+	return p;
+}
 
 // =====================================================================================================
 // mvrt_trace_batch: host-callable batch form of IntersectorOctreeGPU::intersect

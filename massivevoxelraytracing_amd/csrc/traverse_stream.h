@@ -105,6 +105,22 @@ MVRT_DI uint32_t bitMask( uint32_t v, uint32_t bit ) // 0 or 0xFFFFFFFF from bit
 	asm( "v_bfe_i32 %0, %1, %2, 1" : "=v"( r ) : "v"( v ), "v"( bit ) );
 	return r;
 }
+MVRT_DI uint32_t lshlOr( uint32_t a, uint32_t sh, uint32_t c ) // (a << sh) | c  (v_lshl_or_b32)
+{
+	uint32_t r;
+	asm( "v_lshl_or_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( sh ), "v"( c ) );
+	return r;
+}
+MVRT_DI uint32_t andOr( uint32_t a, uint32_t m, uint32_t c ) // (a & m) | c  (v_and_or_b32)
+{
+	uint32_t r;
+	asm( "v_and_or_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( m ), "v"( c ) );
+	return r;
+}
+typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
+typedef uint32_t u4v __attribute__( ( ext_vector_type( 4 ) ) );
+typedef __attribute__( ( address_space( 3 ) ) ) u4v LdsU4; // (u4v: clang vector, assignable across address spaces)
+typedef __attribute__( ( address_space( 3 ) ) ) uint32_t LdsU32;
 MVRT_DI uint32_t bfi( uint32_t mask, uint32_t a, uint32_t b ) // (a & mask) | (b & ~mask)  (v_bfi_b32)
 {
 	uint32_t r;
@@ -240,10 +256,17 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = (uint32_t)total64;
 	const Node64* __restrict__ nodes = s.nodes;
-	uint4* const myRing = ldsRing + lane;	  // slot k at myRing[k * 64]
-	uint4* const mySpill = spill + spillLane; // level L at mySpill[L * spillStride]
-	uint32_t* const myRingMask = EMBED ? nullptr : ldsMask + lane;
-	uint32_t* const mySpillMask = EMBED ? nullptr : spillMask + spillLane;
+	// LDS ring: explicit LDS address space (so the optimiser cannot fold a ring read and a spill read into one flat
+	// load); slot k of this lane at byte offset k * 1024 + lane * 16
+	LdsU4* const myRing = (LdsU4*)ldsRing + lane;
+	const uint32_t ringAddr = (uint32_t)(uintptr_t)myRing; // LDS byte address of this lane's slot 0
+	uint4* const mySpill = spill + spillLane; // level L at mySpill[L * spillStride]  (irregular rays only)
+	LdsU32* const myRingMask = EMBED ? nullptr : (LdsU32*)ldsMask + lane;
+	// spill rows: spillStride is a power of two (traceWorkspaceLanes), rows * stride * 16 B < 4 GiB: row L of this lane
+	// is base + ((L << spillShift) + lane offset) with 32-bit arithmetic and a scalar base
+	const uint32_t spillShift = 4u + (uint32_t)__builtin_ctzll( spillStride );
+	const uint32_t spillOff = (uint32_t)spillLane * 16u;
+	const uint32_t spillMaskShift = spillShift - 2u, spillMaskOff = (uint32_t)spillLane * 4u;
 
 	// wave-uniform cursor state
 	uint32_t chunkNext = 0, chunkEnd = 0;
@@ -254,17 +277,16 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 	bool isShadow = false;
 	uint32_t ray = 0;
 	float dtx = 0, dty = 0, dtz = 0, tx1 = 0, ty1 = 0, tz1 = 0;
-	uint32_t vMask = 0, node = 0, nodeMask = 0, level = 0, childMask = 8u, pending = 0, inLds = 0, descents = 0;
+	uint32_t vMask = 0, vMaskHi = 24u, node = 0, nodeMask = 0, level = 0, childMask = 8u, pending = 0, inLds = 0, descents = 0;
 	uint64_t path = 0;
 	float resT = MVRT_MAXF;
 	int resN = -1;
 
 	for( ;; )
 	{
-		// ---------------- (1) refill ----------------
+		// ---------------- (1) refill: control only gets here when enough lanes are idle ----------------
 		const unsigned long long idleMask = __ballot( st != 1u );
 		const uint32_t nIdle = __popcll( idleMask );
-		if( nIdle == 64 || ( nIdle >= MVRT_REFILL_MIN && !exhausted ) )
 		{
 			if( st == 2u ) // flush results of the lanes that finished since the last refill
 			{
@@ -336,6 +358,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						path = 0;
 						resT = MVRT_MAXF;
 						resN = -1;
+						vMaskHi = vMask | 24u;
 						if( min3f( tx1, ty1, tz1 ) < max3f( t0x, t0y, t0z ) ) // :275-278 misses the root box
 						{
 							st = 2u;
@@ -394,33 +417,42 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			}
 		}
 #endif
-		// ---------------- (2) one traversal step ----------------
+		// ---------------- (2) traversal steps until enough lanes are idle again ----------------
+		// (a clean inner loop: the per-lane state stays in the same registers from one step to the next)
+		for( ;; )
+		{
 		if( st == 1u )
 		{
+			// y and z ride in one register pair so that the slab arithmetic issues as packed fp32 (v_pk_mul_f32 / v_pk_add_f32:
+			// two IEEE operations per issue slot, each rounded exactly like its scalar twin; no contraction)
 			const float scale = mvrt_u2f( ( 127u - level ) << 23 );
+			const v2f t1yz = { ty1, tz1 };
+			const v2f dtyz = { dty, dtz };
 			const float tx0 = tx1 - dtx * scale; // :317-320
-			const float ty0 = ty1 - dty * scale;
-			const float tz0 = tz1 - dtz * scale;
+			const v2f t0yz = t1yz - dtyz * scale;
+			const float ty0 = t0yz.x, tz0 = t0yz.y;
 			// no NaNs can reach here (the direction clamp keeps every product finite), so max3/min3 equal the
 			// reference's compare-select chains up to the sign of a zero, which no decision below can see
 			const float S = fmaxf( fmaxf( tx0, ty0 ), tz0 );
 			const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
-			const float tyM = 0.5f * ( ty0 + ty1 );
-			const float tzM = 0.5f * ( tz0 + tz1 );
+			const v2f tMyz = ( t0yz + t1yz ) * 0.5f;
+			const float tyM = tMyz.x, tzM = tMyz.y;
 			// first visit: childMask bit = (tM < S) = sign bit of (tM - S)  (:342-348; the difference of two
 			// distinct floats is never zero with denormals on, and x - x = +0)
-			const uint32_t cmInit = ( mvrt_f2u( txM - S ) >> 31 ) | ( ( mvrt_f2u( tyM - S ) >> 30 ) & 2u ) | ( ( mvrt_f2u( tzM - S ) >> 29 ) & 4u );
+			const v2f dMyz = tMyz - S;
+			const uint32_t cmInit = ( mvrt_f2u( txM - S ) >> 31 ) | ( ( mvrt_f2u( dMyz.x ) >> 30 ) & 2u ) | ( ( mvrt_f2u( dMyz.y ) >> 29 ) & 4u );
 			const uint32_t cm = bfi( bitMask( childMask, 3 ), cmInit, childMask ); // childMask is either 8 (first visit) or a 3-bit mask
 			const float x1 = mvrt_u2f( bfi( bitMask( cm, 0 ), mvrt_f2u( tx1 ), mvrt_f2u( txM ) ) ); // :358-360
 			const float y1 = mvrt_u2f( bfi( bitMask( cm, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
 			const float z1 = mvrt_u2f( bfi( bitMask( cm, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
 			const float u = fminf( fminf( x1, y1 ), z1 );					  // :365
 			const uint32_t mv = ( u == x1 ) ? 1u : ( ( u == y1 ) ? 2u : 4u ); // :366
-			const uint32_t childIndex = cm ^ vMask;							  // :369
+			const uint32_t childBit = cm ^ vMaskHi;							  // :369, child index + 24 (vMaskHi = vMask | 24)
+			const uint32_t childIndex = childBit & 7u;
 			const uint32_t nextMask = cm | mv;								  // :370
 			const bool leaf = node == MVRT_LEAF;							  // :322
 			const bool hasNext = ( cm & mv ) == 0;							  // :368
-			const bool exists = EMBED ? ( ( node >> ( 24u + childIndex ) ) & 1u ) != 0 : ( ( nodeMask >> childIndex ) & 1u ) != 0;
+			const bool exists = EMBED ? bitMask( node, childBit ) != 0u : ( ( nodeMask >> childIndex ) & 1u ) != 0;
 			const bool go = !leaf && exists && !( u < 0.0f ); // :373-375
 			const bool hit = leaf && ( 0.0f < S );			  // :324
 			const bool pop = leaf ? !hit : ( !go && !hasNext );
@@ -436,17 +468,17 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					if( clash ) // the slot still holds a shallower pending entry: evict it to HBM
 					{
 						const uint32_t lc = __builtin_ctz( clash );
-						mySpill[(uint64_t)lc * spillStride] = myRing[slot * 64];
-						if( !EMBED ) mySpillMask[(uint64_t)lc * spillStride] = myRingMask[slot * 64];
+						*(u4v*)( (char*)spill + ( ( lc << spillShift ) + spillOff ) ) = myRing[slot * 64];
+						if( !EMBED ) *(uint32_t*)( (char*)spillMask + ( ( lc << spillMaskShift ) + spillMaskOff ) ) = myRingMask[slot * 64];
 						inLds &= ~clash;
 					}
-					uint4 e;
+					u4v e;
 					e.x = node;
 					// sign bits of a saved node's exit times are clear (entered with min >= 0; +0 - x and 0.5*(a+b) never
 					// yield -0.0 from non-negative-zero inputs), so the child mask can be OR-ed in without masking
-					e.y = mvrt_f2u( tx1 ) | ( nextMask << 31 );
-					e.z = mvrt_f2u( ty1 ) | ( ( nextMask & 2u ) << 30 );
-					e.w = mvrt_f2u( tz1 ) | ( ( nextMask & 4u ) << 29 );
+					e.y = lshlOr( nextMask, 31u, mvrt_f2u( tx1 ) );
+					e.z = bfi( 0x7FFFFFFFu, mvrt_f2u( ty1 ), nextMask << 30 );
+					e.w = bfi( 0x7FFFFFFFu, mvrt_f2u( tz1 ), nextMask << 29 );
 					myRing[slot * 64] = e;
 					if( !EMBED ) myRingMask[slot * 64] = nodeMask;
 					pending |= 1u << level;
@@ -481,19 +513,24 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				{
 					const uint32_t L = 31u - __builtin_clz( pending );
 					const uint32_t bit = 1u << L;
-					uint4 e = myRing[( L & ( MVRT_RING - 1 ) ) * 64]; // speculative LDS read (valid iff inLds & bit)
+					// speculative LDS read (valid iff inLds & bit).  Issued as asm so that it stays a ds_read: the optimiser
+					// otherwise merges it with the spill read below into one flat load behind an address select
+					u4v ev;
+					asm volatile( "ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"( ev ) : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ) : "memory" );
+					uint4 e = make_uint4( ev.x, ev.y, ev.z, ev.w );
 					if( !EMBED ) nodeMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
-					if( !( inLds & bit ) )
+					if( !( inLds & bit ) ) // rare; the empty asm keeps this a real branch (otherwise: address select + one flat load)
 					{
-						e = mySpill[(uint64_t)L * spillStride];
-						if( !EMBED ) nodeMask = mySpillMask[(uint64_t)L * spillStride];
+						asm volatile( "" ::: "memory" );
+						e = *(const uint4*)( (const char*)spill + ( ( L << spillShift ) + spillOff ) );
+						if( !EMBED ) nodeMask = *(const uint32_t*)( (const char*)spillMask + ( ( L << spillMaskShift ) + spillMaskOff ) );
 					}
 					pending &= ~bit;
 					inLds &= ~bit;
 					path >>= 3u * ( level - L );
 					level = L;
 					node = e.x;
-					childMask = ( e.y >> 31 ) | ( ( e.z >> 30 ) & 2u ) | ( ( e.w >> 29 ) & 4u );
+					childMask = andOr( e.w >> 29, 4u, andOr( e.z >> 30, 2u, e.y >> 31 ) );
 					tx1 = mvrt_u2f( e.y & 0x7FFFFFFFu );
 					ty1 = mvrt_u2f( e.z & 0x7FFFFFFFu );
 					tz1 = mvrt_u2f( e.w & 0x7FFFFFFFu );
@@ -505,6 +542,9 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
 				st = 2u;
 			}
+		}
+		const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
+		if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
 		}
 	}
 }
