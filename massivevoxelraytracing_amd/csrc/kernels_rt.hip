@@ -70,8 +70,11 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 		}
 	}
 }
+#ifndef MVRT_TRACE_WAVES
+#define MVRT_TRACE_WAVES 7 // waves per SIMD the traversal kernels are register-budgeted for (72 VGPRs)
+#endif
 template <bool EMBED>
-__global__ void __launch_bounds__( 64 ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
+__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
 	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
@@ -120,7 +123,7 @@ struct PrimaryIO
 	}
 };
 template <bool EMBED>
-__global__ void __launch_bounds__( 64 ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
+__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
 	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
@@ -639,9 +642,6 @@ struct PtIO
 		nHits += ( kind != 1 && isHit ) ? 1u : 0u;
 	}
 };
-#ifndef MVRT_TRACE_WAVES
-#define MVRT_TRACE_WAVES 1
-#endif
 template <bool EMBED>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
 {
