@@ -40,10 +40,7 @@
 #pragma once
 #include "mvrt_common.h"
 
-#ifndef MVRT_RING
-#define MVRT_RING 4 // LDS ring slots per lane (4 or 8)
-#endif
-#define MVRT_RING_CLASH ( MVRT_RING == 4 ? 0x11111111u : 0x01010101u ) // the levels that share ring slot 0
+#define MVRT_RING 4			// LDS ring slots per lane
 #ifndef MVRT_REFILL_MIN
 #define MVRT_REFILL_MIN 20 // refill once this many lanes are idle (or all of them)
 #endif
@@ -118,6 +115,29 @@ MVRT_DI uint32_t andOr( uint32_t a, uint32_t m, uint32_t c ) // (a & m) | c  (v_
 {
 	uint32_t r;
 	asm( "v_and_or_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( m ), "v"( c ) );
+	return r;
+}
+typedef unsigned long long lmask;						   // one bit per lane, wave-uniform (SGPR pair)
+#define LANE( m ) __builtin_amdgcn_inverse_ballot_w64( m ) // this lane's bit of a lane mask, as a select condition
+// lane select on a lane mask held in an SGPR pair: one v_cndmask_b32, issued as asm so that the optimiser cannot regroup a
+// run of selects into an exec-masked block behind a skip branch
+MVRT_DI uint32_t selU( lmask m, uint32_t a, uint32_t b ) // lane bit set ? a : b
+{
+	uint32_t r;
+	asm( "v_cndmask_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( b ), "v"( a ), "s"( m ) );
+	return r;
+}
+MVRT_DI uint32_t selUAfter( lmask m, uint32_t a, uint32_t b, float after ) // selU that cannot be scheduled before `after` exists
+{
+	uint32_t r;
+	asm( "v_cndmask_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( b ), "v"( a ), "s"( m ), "v"( after ) );
+	return r;
+}
+MVRT_DI float selF( lmask m, float a, float b ) { return mvrt_u2f( selU( m, mvrt_f2u( a ), mvrt_f2u( b ) ) ); }
+MVRT_DI float selAbsF( lmask m, uint32_t aBits, float b ) // lane bit set ? |a| : b   (sign bit of a carries a flag)
+{
+	float r;
+	asm( "v_cndmask_b32 %0, %1, |%2|, %3" : "=v"( r ) : "v"( b ), "v"( aBits ), "s"( m ) );
 	return r;
 }
 typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
@@ -263,6 +283,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 	// load); slot k of this lane at byte offset k * 1024 + lane * 16
 	LdsU4* const myRing = (LdsU4*)ldsRing + lane;
 	const uint32_t ringAddr = (uint32_t)(uintptr_t)myRing; // LDS byte address of this lane's slot 0
+	const uint32_t ringMaskAddr = EMBED ? 0u : (uint32_t)(uintptr_t)( (LdsU32*)ldsMask + lane );
 	uint4* const mySpill = spill + spillLane; // level L at mySpill[L * spillStride]  (irregular rays only)
 	LdsU32* const myRingMask = EMBED ? nullptr : (LdsU32*)ldsMask + lane;
 	// spill rows: spillStride is a power of two (traceWorkspaceLanes), rows * stride * 16 B < 4 GiB: row L of this lane
@@ -421,10 +442,22 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		}
 #endif
 		// ---------------- (2) traversal steps until enough lanes are idle again ----------------
-		// (a clean inner loop: the per-lane state stays in the same registers from one step to the next)
+		// BRANCH-FREE step.  On gfx950 a branch instruction -- taken or not, s_cbranch_execz included -- costs the SIMD
+		// about as much issue time as four VALU instructions (tools/calib/issue_rate.hip), and the compiler wraps every
+		// divergent `if` that contains a memory instruction in one.  So the step has no `if`: every lane executes the
+		// same instruction stream; the three outcomes (descend [+push] / pop / hit) are lane predicates that drive
+		// selects, and the memory instructions run under an explicit exec mask (inline asm) or on a harmless address.
+		//  * push is WRITE-THROUGH: the entry goes to its LDS ring slot and to its spill row in one masked pair of
+		//    instructions, so a ring slot can be overwritten without first evicting what it held (no clash test);
+		//  * pop reads the ring slot of the deepest pending level for every lane, then re-loads the lanes whose entry
+		//    has been overwritten from the spill row under an exec mask.  That load carries sc0 sc1 (served by L2): a
+		//    64-byte line of a spill row holds the entries of four neighbouring lanes, and a copy of it in the CU's L1
+		//    -- fetched for one lane -- would not see what the other three have stored since;
+		//  * the child-pointer load of this step is consumed at the top of the NEXT step (after the slab arithmetic,
+		//    which does not depend on it), so its latency overlaps with that arithmetic.
+		uint32_t loadedPrev = 0, loadedPrev2 = 0, maskShiftPrev = 0;
+		lmask mGoPrev = 0, mActive = __ballot( st == 1u );
 		for( ;; )
-		{
-		if( st == 1u )
 		{
 			// y and z ride in one register pair so that the slab arithmetic issues as packed fp32 (v_pk_mul_f32 / v_pk_add_f32:
 			// two IEEE operations per issue slot, each rounded exactly like its scalar twin; no contraction)
@@ -434,8 +467,8 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const float tx0 = tx1 - dtx * scale; // :317-320
 			const v2f t0yz = t1yz - dtyz * scale;
 			const float ty0 = t0yz.x, tz0 = t0yz.y;
-			// no NaNs can reach here (the direction clamp keeps every product finite), so max3/min3 equal the
-			// reference's compare-select chains up to the sign of a zero, which no decision below can see
+			// no NaNs can reach the decisions of an active lane (the direction clamp keeps every product finite), so max3/min3
+			// equal the reference's compare-select chains up to the sign of a zero, which no decision below can see
 			const float S = fmaxf( fmaxf( tx0, ty0 ), tz0 );
 			const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
 			const v2f tMyz = ( t0yz + t1yz ) * 0.5f;
@@ -453,101 +486,161 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const uint32_t childBit = cm ^ vMaskHi;							  // :369, child index + 24 (vMaskHi = vMask | 24)
 			const uint32_t childIndex = childBit & 7u;
 			const uint32_t nextMask = cm | mv;								  // :370
-			const bool leaf = node == MVRT_LEAF;							  // :322
-			const bool hasNext = ( cm & mv ) == 0;							  // :368
-			const bool exists = EMBED ? bitMask( node, childBit ) != 0u : ( ( nodeMask >> childIndex ) & 1u ) != 0;
-			const bool go = !leaf && exists && !( u < 0.0f ); // :373-375
-			const bool hit = leaf && ( 0.0f < S );			  // :324
-			const bool pop = leaf ? !hit : ( !go && !hasNext );
-			// advance within the node (:396-411): only the child mask changes
-			childMask = leaf ? childMask : ( ( !go && hasNext ) ? nextMask : cm );
+			// the child pointer fetched by the previous step lands here (:381)
+			// (the select is tied to `u` so that the scheduler cannot hoist it -- and the wait for the load -- above the arithmetic)
+			node = selUAfter( mGoPrev, loadedPrev, node, u );
+			if( !EMBED ) nodeMask = selUAfter( mGoPrev, ( loadedPrev2 >> maskShiftPrev ) & 0xFFu, nodeMask, u );
+			// lane predicates as 64-bit lane masks: the logic runs on the scalar unit and every select below takes its mask
+			// straight from an SGPR pair (written with && / ?: on bools it comes back as short-circuit branches)
+			const lmask mLeaf = __ballot( node == MVRT_LEAF );	 // :322
+			const lmask mHasNext = __ballot( ( cm & mv ) == 0u ); // :368
+			const lmask mExists = __ballot( EMBED ? bitMask( node, childBit ) != 0u : ( ( nodeMask >> childIndex ) & 1u ) != 0u );
+			const lmask mGo = mActive & ~mLeaf & mExists & ~__ballot( u < 0.0f ); // :373-375
+			const lmask mHit = mActive & mLeaf & __ballot( 0.0f < S );			   // :324
+			const lmask mPop = mActive & ~mHit & ~mGo & ( mLeaf | ~mHasNext );
+			const lmask mAdv = mActive & ~mLeaf & ~mGo & mHasNext;
+			childMask = selU( mAdv, nextMask, cm ); // advance within the node (:396-411): only the child mask changes
 
-			if( go )
+			// ---- pop (:414-422) ----
+			lmask mMissOut;
 			{
-				if( hasNext ) // push (:377-380)
-				{
-					const uint32_t slot = level & ( MVRT_RING - 1 );
-					const uint32_t clash = inLds & ( MVRT_RING_CLASH << slot );
-					if( clash ) // the slot still holds a shallower pending entry: evict it to HBM
-					{
-						const uint32_t lc = __builtin_ctz( clash );
-						*(u4v*)( (char*)spill + ( ( lc << spillShift ) + spillOff ) ) = myRing[slot * 64];
-						if( !EMBED ) *(uint32_t*)( (char*)spillMask + ( ( lc << spillMaskShift ) + spillMaskOff ) ) = myRingMask[slot * 64];
-						inLds &= ~clash;
-					}
-					u4v e;
-					e.x = node;
-					// sign bits of a saved node's exit times are clear (entered with min >= 0; +0 - x and 0.5*(a+b) never
-					// yield -0.0 from non-negative-zero inputs), so the child mask can be OR-ed in without masking
-					e.y = lshlOr( nextMask, 31u, mvrt_f2u( tx1 ) );
-					e.z = bfi( 0x7FFFFFFFu, mvrt_f2u( ty1 ), nextMask << 30 );
-					e.w = bfi( 0x7FFFFFFFu, mvrt_f2u( tz1 ), nextMask << 29 );
-					myRing[slot * 64] = e;
-					if( !EMBED ) myRingMask[slot * 64] = nodeMask;
-					pending |= 1u << level;
-					inLds |= 1u << level;
-				}
+				const uint32_t L = ( 31u - (uint32_t)__clz( (int)pending ) ) & 31u; // deepest pending level (any value when none)
+				const uint32_t bit = 1u << L;
+				const lmask mPending = __ballot( pending != 0u );
+				const lmask mPopOk = mPop & mPending, mMiss = mPop & ~mPending;
+				const lmask mSpill = mPopOk & __ballot( ( inLds & bit ) == 0u );
+				const bool popOk = LANE( mPopOk );
+				mMissOut = mMiss;
+				u4v e;
+				uint32_t eMask = 0;
+				unsigned long long sv;
 				if( EMBED )
 				{
-					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
-					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
+					asm volatile( "ds_read_b128 %0, %2\n\t"
+								  "s_and_saveexec_b64 %1, %3\n\t"
+								  "s_waitcnt lgkmcnt(0)\n\t"
+								  "s_cbranch_execz .Lnospill%=\n\t" // rare path: skipped by a branch (an exec = 0 load would still cost a round trip)
+								  "global_load_dwordx4 %0, %4, %5 sc0 sc1\n\t"
+								  "s_waitcnt vmcnt(0)\n"
+								  ".Lnospill%=:\n\t"
+								  "s_mov_b64 exec, %1"
+								  : "=&v"( e ), "=&s"( sv )
+								  : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ), "s"( mSpill ), "v"( ( L << spillShift ) + spillOff ), "s"( spill )
+								  : "memory", "scc" );
 				}
 				else
 				{
-					const Node64* nd = nodes + node; // up to 2^32 nodes: 64-bit addressing
-					nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu; // the child's mask: same line as
-					node = nd->children[childIndex];												 // its pointer
+					asm volatile( "ds_read_b128 %0, %3\n\t"
+								  "ds_read_b32 %1, %4\n\t"
+								  "s_and_saveexec_b64 %2, %5\n\t"
+								  "s_waitcnt lgkmcnt(0)\n\t"
+								  "s_cbranch_execz .Lnospill%=\n\t"
+								  "global_load_dwordx4 %0, %6, %7 sc0 sc1\n\t"
+								  "global_load_dword %1, %8, %9 sc0 sc1\n\t"
+								  "s_waitcnt vmcnt(0)\n"
+								  ".Lnospill%=:\n\t"
+								  "s_mov_b64 exec, %2"
+								  : "=&v"( e ), "=&v"( eMask ), "=&s"( sv )
+								  : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ), "v"( ringMaskAddr + ( ( L & ( MVRT_RING - 1 ) ) << 8 ) ), "s"( mSpill ),
+									"v"( ( L << spillShift ) + spillOff ), "s"( spill ), "v"( ( L << spillMaskShift ) + spillMaskOff ), "s"( spillMask )
+								  : "memory", "scc" );
 				}
-				descents++;
-				path = ( path << 3 ) | childIndex;
-				tx1 = x1; // :382-386
-				ty1 = y1;
-				tz1 = z1;
-				level++;
-				childMask = 8u;
+				const uint32_t cmR = andOr( e.w >> 29, 4u, andOr( e.z >> 30, 2u, e.y >> 31 ) );
+				st = selU( mMiss | mHit, 2u, st ); // miss (the stack is empty) or hit: the lane holds its result until the next refill
+				node = selU( mPopOk, e.x, node );
+				if( !EMBED ) nodeMask = selU( mPopOk, eMask, nodeMask );
+				childMask = selU( mPopOk, cmR, childMask );
+				tx1 = selAbsF( mPopOk, e.y, tx1 );
+				ty1 = selAbsF( mPopOk, e.z, ty1 );
+				tz1 = selAbsF( mPopOk, e.w, tz1 );
+				const uint32_t up = selU( mPopOk, 3u * ( level - L ), 0u );
+				path >>= up;
+				level = selU( mPopOk, L, level );
+				const uint32_t clr = popOk ? bit : 0u;
+				pending &= ~clr;
+				inLds &= ~clr;
 			}
-			if( pop ) // :414-422
+
+			// ---- descend (:377-391), with a write-through push when the node has further candidates ----
 			{
-				if( pending == 0 ) // miss
+				const lmask mPush = mGo & mHasNext;
+				const bool push = LANE( mPush ), go = LANE( mGo );
+				const uint32_t slot = level & ( MVRT_RING - 1 );
+				u4v en;
+				en.x = node;
+				// sign bits of a saved node's exit times are clear (entered with min >= 0; +0 - x and 0.5*(a+b) never
+				// yield -0.0 from non-negative-zero inputs), so they can carry the child mask
+				en.y = lshlOr( nextMask, 31u, mvrt_f2u( tx1 ) );
+				en.z = bfi( 0x7FFFFFFFu, mvrt_f2u( ty1 ), nextMask << 30 );
+				en.w = bfi( 0x7FFFFFFFu, mvrt_f2u( tz1 ), nextMask << 29 );
+				unsigned long long sv;
+				if( EMBED )
 				{
-					st = 2u;
+					asm volatile( "s_and_saveexec_b64 %0, %1\n\t"
+								  "ds_write_b128 %2, %3\n\t"
+								  "global_store_dwordx4 %4, %3, %5\n\t"
+								  "s_mov_b64 exec, %0\n\t"
+								  "s_nop 1" // gfx940+: a VALU write of the data VGPRs of a >8-byte store needs 2 wait states; the
+											// compiler cannot see the store inside this block, so the padding is written here
+								  : "=&s"( sv )
+								  : "s"( mPush ), "v"( ringAddr + ( slot << 10 ) ), "v"( en ), "v"( ( level << spillShift ) + spillOff ), "s"( spill )
+								  : "memory", "scc" );
 				}
 				else
 				{
-					const uint32_t L = 31u - __builtin_clz( pending );
-					const uint32_t bit = 1u << L;
-					// speculative LDS read (valid iff inLds & bit).  Issued as asm so that it stays a ds_read: the optimiser
-					// otherwise merges it with the spill read below into one flat load behind an address select
-					u4v ev;
-					asm volatile( "ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"( ev ) : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ) : "memory" );
-					uint4 e = make_uint4( ev.x, ev.y, ev.z, ev.w );
-					if( !EMBED ) nodeMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
-					if( !( inLds & bit ) ) // rare; the empty asm keeps this a real branch (otherwise: address select + one flat load)
-					{
-						asm volatile( "" ::: "memory" );
-						e = *(const uint4*)( (const char*)spill + ( ( L << spillShift ) + spillOff ) );
-						if( !EMBED ) nodeMask = *(const uint32_t*)( (const char*)spillMask + ( ( L << spillMaskShift ) + spillMaskOff ) );
-					}
-					pending &= ~bit;
-					inLds &= ~bit;
-					path >>= 3u * ( level - L );
-					level = L;
-					node = e.x;
-					childMask = andOr( e.w >> 29, 4u, andOr( e.z >> 30, 2u, e.y >> 31 ) );
-					tx1 = mvrt_u2f( e.y & 0x7FFFFFFFu );
-					ty1 = mvrt_u2f( e.z & 0x7FFFFFFFu );
-					tz1 = mvrt_u2f( e.w & 0x7FFFFFFFu );
+					asm volatile( "s_and_saveexec_b64 %0, %1\n\t"
+								  "ds_write_b128 %2, %3\n\t"
+								  "ds_write_b32 %4, %5\n\t"
+								  "global_store_dwordx4 %6, %3, %7\n\t"
+								  "global_store_dword %8, %5, %9\n\t"
+								  "s_mov_b64 exec, %0\n\t"
+								  "s_nop 1"
+								  : "=&s"( sv )
+								  : "s"( mPush ), "v"( ringAddr + ( slot << 10 ) ), "v"( en ), "v"( ringMaskAddr + ( slot << 8 ) ), "v"( nodeMask ),
+									"v"( ( level << spillShift ) + spillOff ), "s"( spill ), "v"( ( level << spillMaskShift ) + spillMaskOff ), "s"( spillMask )
+								  : "memory", "scc" );
 				}
+				const uint32_t lb = push ? 1u << level : 0u;
+				pending |= lb;
+				inLds = bfi( push ? ( 0x11111111u << slot ) : 0u, lb, inLds ); // the slot now holds level `level` and nothing shallower
+				// child pointer (and, non-embedded, the child masks that sit in the same line); lanes that do not descend read
+				// the first dword of the node array
+				if( EMBED )
+				{
+					const uint32_t off = go ? ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) : 0u;
+					loadedPrev = *(const uint32_t*)( (const char*)nodes + off ); // 32-bit offset from the uniform base
+				}
+				else
+				{
+					const uint64_t off = go ? ( (uint64_t)node << 6 ) : 0ull; // up to 2^32 nodes: 64-bit addressing
+					const Node64* nd = (const Node64*)( (const char*)nodes + off );
+					loadedPrev = nd->children[childIndex];
+					loadedPrev2 = nd->psum[childIndex >> 2]; // 4 child masks; the right byte is picked when the pointer is consumed
+					maskShiftPrev = 8u * ( childIndex & 3u );
+				}
+				const uint32_t one = selU( mGo, 1u, 0u );
+				descents += one;
+				path = ( path << ( 3u * one ) ) | selU( mGo, childIndex, 0u );
+				tx1 = selF( mGo, x1, tx1 ); // :382-386
+				ty1 = selF( mGo, y1, ty1 );
+				tz1 = selF( mGo, z1, tz1 );
+				level += one;
+				childMask = selU( mGo, 8u, childMask );
 			}
-			if( hit ) // :324-334
-			{
-				resT = S;
-				resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
-				st = 2u;
-			}
+
+			// ---- hit (:324-334) ----
+			const int nmY = ( S == ty0 ) ? 2 : 0;
+			const int nm = ( S == tx0 ) ? 1 : nmY;
+			resT = selF( mHit, S, resT );
+			resN = (int)selU( mHit, (uint32_t)nm, (uint32_t)resN );
+
+			mGoPrev = mGo;
+			mActive &= ~( mMissOut | mHit );
+			const int nDone = 64 - __builtin_popcountll( mActive );
+			if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
 		}
-		const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
-		if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
-		}
+		// the last step's child pointer is still in flight for the lanes that descended
+		node = LANE( mGoPrev ) ? loadedPrev : node;
+		if( !EMBED ) nodeMask = LANE( mGoPrev ) ? ( ( loadedPrev2 >> maskShiftPrev ) & 0xFFu ) : nodeMask;
 	}
 }
