@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+RANDOM_LINE_CEILING_GBS = 3200.0  # measured on the box: 50 G random 64-byte lines per second (tools/calib/gather_rate.hip)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured copy)
 
 
@@ -76,7 +77,11 @@ def stress(args, mv):
                    "embedded_mask": int(info.embeddedMask), "svo_build_s": round(build_s, 2), "hits": hits, "descents_per_ray": round(float(desc.mean()), 2)},
         "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<false>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
-                     "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts the 64-byte node line each descent pulls from HBM"},
+                     "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "random_line_ceiling_gbs": RANDOM_LINE_CEILING_GBS,
+                     "line_frac_of_ceiling": round(line_bytes * args.steps / el / 1e9 / RANDOM_LINE_CEILING_GBS, 3),
+                     "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts the 64-byte node line each descent pulls from HBM; "
+                             "random_line_ceiling_gbs = what the chip serves for divergent 64-byte-line gathers at 128 GiB footprint "
+                             "(tools/calib/gather_rate.hip, profiles/r01_gfx950_issue_and_gather_costs.txt)"},
     }), flush=True)
 
 
