@@ -682,12 +682,16 @@ struct mvrt_pt
 		if( e ) depth = atoi( e );
 		if( depth < 1 ) depth = 1;
 		if( depth > 4 ) depth = 4;
+		const char* sp = getenv( "MVRT_SPLIT_SMALL" );
+		if( sp ) splitSmallPasses = atoi( sp ) != 0;
 		const char* b = getenv( "MVRT_BATCH_STEPS" );
 		if( b ) batch = atoi( b );
 		if( batch < 0 ) batch = 0;
 		if( batch > MVRT_MAX_BATCH ) batch = MVRT_MAX_BATCH;
 	}
 	int flush(); // launch the pending steps (defined below)
+	int launchPass( const CameraPinhole* passCams, int iteration, int nSteps, int traceGridDiv );
+	bool splitSmallPasses = true; // MVRT_SPLIT_SMALL=0 disables (A/B)
 	int effectiveBatch() const // merged steps per pass, bounded so that one pass stays below ~160 M samples (~30 GB of path state)
 	{
 		uint64_t perStep = ownedPixels * MVRT_SPP_PER_STEP;
@@ -1010,8 +1014,25 @@ MVRT_EXPORT int mvrt_pt_step( mvrt_pt* pt, void* stream, const float camera[15] 
 }
 int mvrt_pt::flush()
 {
-	mvrt_pt* pt = this;
 	if( pendingCams.empty() ) return 0;
+	const int n = (int)pendingCams.size();
+	// A SMALL pass (a tile share of a multi-GPU frame, a small frame) is dominated by the latency floors of its nine traversal
+	// launches and by its un-overlapped shade kernels.  Two sibling passes on two streams, each traversal launch restricted to half
+	// of the wave slots, overlap one pass's tails and shading with the other's traversal.  Same per-sample results; the frame-buffer
+	// additions stay in step order through the event chain.
+	const uint64_t samples = ownedPixels * MVRT_SPP_PER_STEP * (uint64_t)n;
+	const bool split = splitSmallPasses && depth >= 2 && n >= 2 && samples <= 40000000ull;
+	std::vector<CameraPinhole> cams( pendingCams );
+	const int first = pendingIteration;
+	pendingCams.clear();
+	if( !split ) return launchPass( cams.data(), first, n, 1 );
+	const int n0 = n / 2;
+	if( launchPass( cams.data(), first, n0, 2 ) ) return 1;
+	return launchPass( cams.data() + n0, first + n0, n - n0, 2 );
+}
+int mvrt_pt::launchPass( const CameraPinhole* passCams, int iteration, int nSteps, int traceGridDiv )
+{
+	mvrt_pt* pt = this;
 	PtFrame f;
 	f.width = width;
 	f.height = height;
@@ -1019,11 +1040,11 @@ int mvrt_pt::flush()
 	f.tileCount = tileCount;
 	f.ownedPixels = ownedPixels;
 	f.validOwnedPixels = validOwnedPixels;
-	f.iteration = pendingIteration;
-	f.nSteps = (int)pendingCams.size();
+	f.iteration = iteration;
+	f.nSteps = nSteps;
+	f.traceGridDiv = traceGridDiv;
 	CameraPinhole cams[MVRT_MAX_BATCH];
-	for( int b = 0; b < f.nSteps; b++ ) cams[b] = pendingCams[b];
-	pendingCams.clear();
+	for( int b = 0; b < f.nSteps; b++ ) cams[b] = passCams[b];
 	hipStream_t user = pendingStream;
 	mvrt_pt::Slot& sl = pt->slots[pt->nextSlot];
 	pt->lastSlot = pt->nextSlot;

@@ -1012,7 +1012,14 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		PROF_BEGIN( MVRT_K_TRACE );
 		if( ws.spill )
 		{
-			const int g = streamGrid( nSamples * nKinds, nCUs );
+			int g = streamGrid( nSamples * nKinds, nCUs );
+			{
+				// a pass that shares the GPU with a sibling pass on another stream takes only 1/div of the wave slots, so that the two
+				// really run side by side (a full persistent grid would hold every slot until its own tail)
+				static const int envDiv = getenv( "MVRT_TRACE_GRID_DIV" ) ? atoi( getenv( "MVRT_TRACE_GRID_DIV" ) ) : 0;
+				const int div = envDiv > 0 ? envDiv : frame.traceGridDiv;
+				if( div > 1 && g > nCUs * STREAM_WAVES_PER_CU / div ) g = nCUs * STREAM_WAVES_PER_CU / div;
+			}
 			if( svo.embedded )
 				hipLaunchKernelGGL( kPtTraceStream<true>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
 			else

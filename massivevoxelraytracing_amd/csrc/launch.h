@@ -43,6 +43,7 @@ struct PtFrame
 	uint64_t validOwnedPixels; // pixels that exist in the image
 	int iteration;			   // iteration of the first step of this batch
 	int nSteps;				   // consecutive step() calls merged into this wavefront pass (1..MVRT_MAX_BATCH)
+	int traceGridDiv;		   // >1: the traversal launches of this pass take only 1/div of the wave slots (it shares the GPU with a sibling pass)
 };
 #define MVRT_MAX_BATCH 8
 
