@@ -164,6 +164,10 @@ int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth );
  * wavefront pass -- larger launches, identical per-sample results, additions to the frame buffer still step by step.
  * Any consumer (resolve, to_image, read, clear, join, get_stats ...) launches what is pending first. */
 int mvrt_pt_set_batch_steps( mvrt_pt* pt, int maxSteps );
+/* A SMALL pass (<= 40 M samples: a tile share of a multi-GPU frame, a small frame) of >= 2 merged steps is launched as two sibling
+ * passes on two internal streams, each traversal launch restricted to half of the wave slots, so that the launch tails and the
+ * shading of one overlap with the traversal of the other (default on; needs pipeline depth >= 2).  Results are unchanged. */
+int mvrt_pt_set_split_small_passes( mvrt_pt* pt, int enable );
 int mvrt_pt_join( mvrt_pt* pt, void* stream );
 int mvrt_pt_resolve( mvrt_pt* pt, void* stream );						/* :130-137, renderResolve */
 int mvrt_pt_to_image_async( mvrt_pt* pt, void* stream, uint8_t* rgbaHost ); /* :118-129 resolve + DtoH (caller syncs) */

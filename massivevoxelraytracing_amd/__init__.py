@@ -79,6 +79,7 @@ SIGNATURES = {
     "mvrt_pt_step_matrices": (_i32, [_vp, _vp, _vp, _vp, _f32, _f32]),
     "mvrt_pt_set_pipeline_depth": (_i32, [_vp, _i32]),
     "mvrt_pt_set_batch_steps": (_i32, [_vp, _i32]),
+    "mvrt_pt_set_split_small_passes": (_i32, [_vp, _i32]),
     "mvrt_pt_join": (_i32, [_vp, _vp]),
     "mvrt_pt_resolve": (_i32, [_vp, _vp]),
     "mvrt_pt_to_image_async": (_i32, [_vp, _vp, _vp]),
@@ -401,6 +402,9 @@ class PathTracer:
 
     def set_batch_steps(self, n):
         _check(lib().mvrt_pt_set_batch_steps(self._h, n))
+
+    def set_split_small_passes(self, enable):
+        _check(lib().mvrt_pt_set_split_small_passes(self._h, 1 if enable else 0))
 
     def set_pipeline_depth(self, depth):
         _check(lib().mvrt_pt_set_pipeline_depth(self._h, depth))

@@ -1132,6 +1132,13 @@ MVRT_EXPORT int mvrt_pt_set_batch_steps( mvrt_pt* pt, int maxSteps )
 	if( pt->fbF32.p ) return allocWork( pt );
 	return 0;
 }
+MVRT_EXPORT int mvrt_pt_set_split_small_passes( mvrt_pt* pt, int enable )
+{
+	REQUIRE( pt, "null argument" );
+	if( pt->drain() ) return 1;
+	pt->splitSmallPasses = enable != 0;
+	return 0;
+}
 MVRT_EXPORT int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth )
 {
 	REQUIRE( pt && depth >= 1 && depth <= 4, "pipeline depth must be 1..4" );

@@ -643,6 +643,11 @@ __global__ void __launch_bounds__( BB ) kMakeNodesDirect( const Task* __restrict
 // distinct parents per level for ALL levels in one pass (the reference's octreeTaskInit counters, voxKernel.cu:257-265)
 __global__ void __launch_bounds__( BB ) kLevelCounts( const uint64_t* __restrict__ morton, uint64_t n, int levels, unsigned long long* __restrict__ counts )
 {
+	// per-workgroup tallies in LDS, one global atomic per level and workgroup at the end (13 hot addresses took 0.64 s of global
+	// atomics for 650 M voxels when every wave added to them directly)
+	__shared__ unsigned int tally[32];
+	if( threadIdx.x < 32 ) tally[threadIdx.x] = 0u;
+	__syncthreads();
 	for( uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BB )
 	{
 		const uint64_t a = morton[i], b = i ? morton[i - 1] : 0;
@@ -650,9 +655,11 @@ __global__ void __launch_bounds__( BB ) kLevelCounts( const uint64_t* __restrict
 		{
 			const bool head = i == 0 || ( a >> ( 3 * ( l + 1 ) ) ) != ( b >> ( 3 * ( l + 1 ) ) );
 			const unsigned long long m = __ballot( head );
-			if( head && ( threadIdx.x & 63 ) == (uint32_t)__builtin_ctzll( m ) ) atomicAdd( &counts[l], (unsigned long long)__popcll( m ) );
+			if( head && ( threadIdx.x & 63 ) == (uint32_t)__builtin_ctzll( m ) ) atomicAdd( &tally[l], (unsigned int)__popcll( m ) );
 		}
 	}
+	__syncthreads();
+	if( threadIdx.x < (uint32_t)levels && tally[threadIdx.x] ) atomicAdd( &counts[threadIdx.x], (unsigned long long)tally[threadIdx.x] );
 }
 // seeded synthetic voxels: uniformly random cells of the grid with hash-derived colours; ~1/256 of them emissive
 MVRT_HDI uint64_t splitmix64( uint64_t x )

@@ -323,3 +323,21 @@ def test_deferred_batched_steps_with_moving_camera(mv, O, bunny256_color, hdr, b
         rays += cnt["rays"]
     assert np.array_equal(got, fb)
     assert pt.stats()["rays"] == rays
+
+
+def test_split_small_passes_is_result_neutral(mv, O, bunny256_color, hdr):
+    """a small multi-step pass launched as two sibling passes with half-grid traversal launches (the default) gives the same
+    frame buffer and ray counts as one full-grid pass, bit for bit"""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h, iters = 192, 108, 6
+    cams = [probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.03, offset=(6 - 0.3 * i, 4, 6)) for i in range(iters)]
+    out = []
+    for enable in (True, False):
+        pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+        pt.set_split_small_passes(enable)
+        for c in cams:
+            pt.step(None, c)
+        out.append((pt.read_framebuffer()[: w * h].copy(), pt.stats()["rays"]))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert out[0][0][:, 3].min() == 16 * iters
