@@ -861,6 +861,10 @@ struct TraceStats
 	uint64_t descents;
 	int maxSp;
 };
+// traversal event tallies over every ray traced with stats (diagnostics for the kernel design, read by orc_trace_events):
+// [0] rays, [1] candidate tests (inner-loop turns), [2] descents, [3] pushes, [4] pops, [5] pops that were followed by a descent
+// from the restored node before the next pop ("fruitful"), [6] leaf checks, [7] node visits (outer-loop turns on inner nodes)
+static std::atomic<uint64_t> g_events[8];
 
 static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_t nodeIndex, StackElement* stack, float3 ro, float3 rd, const float3& lower,
 												const float3& upper, float* t, int* nMajor, uint32_t* vIndex, bool isShadowRay, bool embedded, TraceStats* stats )
@@ -895,6 +899,8 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 	if( embedded ) nodeIndex |= (uint32_t)nodes[nodeIndex].mask << 24; // :306
 
 	int sp = 0;
+	uint64_t ev[8] = { 1, 0, 0, 0, 0, 0, 0, 0 };
+	bool justPopped = false;
 	StackElement cur = { nodeIndex, t1.x, t1.y, t1.z, 1.0f, 0xFFFFFFFF, 0, 0 }; // :310
 	float3 dt = t1 - t0;													   // :312
 
@@ -909,6 +915,7 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 		bool descended = false;
 		if( cur.nodeIndex == 0xFFFFFFFFu ) // :322
 		{
+			ev[6]++;
 			if( 0.0f < S_lmax )
 			{
 				*t = S_lmax;
@@ -920,6 +927,7 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 		}
 		else
 		{
+			ev[7]++;
 			float txM = 0.5f * ( tx0 + cur.tx1 ); // :338-340
 			float tyM = 0.5f * ( ty0 + cur.ty1 );
 			float tzM = 0.5f * ( tz0 + cur.tz1 );
@@ -944,6 +952,7 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 			float z1 = ( cur.childMask & 4u ) ? cur.tz1 : tzM;
 			for( ;; ) // :362-412
 			{
+				ev[1]++;
 				float S_umin_next = minElement( x1, y1, z1 );
 				uint32_t mv = S_umin_next == x1 ? 1u : ( S_umin_next == y1 ? 2u : 4u );
 				bool hasNext = ( cur.childMask & mv ) == 0;
@@ -955,10 +964,14 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 					if( hasNext )
 					{
 						stack[sp++] = cur;
+						ev[3]++;
 						if( stats && sp > stats->maxSp ) stats->maxSp = sp;
 					}
 					cur.nodeIndex = node->children[childIndex];
 					if( stats ) stats->descents++;
+					ev[2]++;
+					if( justPopped ) ev[5]++;
+					justPopped = false;
 					cur.tx1 = x1;
 					cur.ty1 = y1;
 					cur.tz1 = z1;
@@ -982,8 +995,23 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 		}
 		if( descended ) continue;
 		// pop: (:414-422)
-		if( sp ) cur = stack[--sp];
+		if( sp )
+		{
+			cur = stack[--sp];
+			ev[4]++;
+			justPopped = true;
+		}
 		else break;
+	}
+	if( stats )
+		for( int k = 0; k < 8; k++ ) g_events[k].fetch_add( ev[k], std::memory_order_relaxed );
+}
+ORC_API void orc_trace_events( uint64_t out[8], int reset )
+{
+	for( int k = 0; k < 8; k++ )
+	{
+		out[k] = g_events[k].load();
+		if( reset ) g_events[k].store( 0 );
 	}
 }
 
