@@ -12,16 +12,21 @@
 //
 // Same results as traverse.h / the reference's octreeTraverse_EfficientParametric
 // (voxCommon.hpp:231-423): identical slab arithmetic, child order, tie-breaks and hit test.  What is
-// different is everything the hardware cares about.  Measured on MI355X the traversal is LATENCY
-// bound -- throughput is proportional to resident waves per CU (profiles/r01_occupancy_sweep.txt) --
-// so this kernel is built around residency and lane utilisation:
+// different is everything the hardware cares about.  Measured on MI355X (DESIGN.md 5.3,
+// profiles/r01_gfx950_issue_and_gather_costs.txt): on cache-resident DAG octrees the step is bound by instruction
+// issue -- a VOP3 instruction costs the SIMD ~4.4 cycles, a branch ~10, and the ONE scalar ALU of a CU is shared by its
+// four SIMDs (~3 cycles of a SIMD's time per SALU instruction once it saturates) -- and on an HBM-resident octree by
+// the chip's random-line rate (50 G lines/s).  The kernel is built around few instructions per NODE VISIT, residency
+// and lane utilisation:
 //
+//  * one loop iteration settles a whole node visit (all candidate children at once, see the step below) instead of one
+//    candidate child as the reference's inner loop does, and pushes a node only when a later valid candidate exists;
 //  * 16-byte stack entries.  The reference saves 32 bytes per level (voxCommon.hpp:202-212).  Here:
 //      - slot index = tree level of the saved node.  Pending entries are ancestors of the current node,
 //        hence at strictly increasing levels, so "which entries are pending" is a 32-bit mask in a
 //        register; pop = highest set bit.  Neither sp nor the level is stored.
 //      - scale = 2^-level is rebuilt from the level.
-//      - childMask (3 bits) rides in the sign bits of tx1/ty1/tz1: a saved node was entered with
+//      - the child a node is left through (3 bits) rides in the sign bits of tx1/ty1/tz1: a saved node was entered with
 //        min(x1,y1,z1) >= 0, so its exit times are never negative (a -0.0 would come back as +0.0,
 //        which no comparison or output can distinguish).
 //      - nVoxelSkipped is not saved at all: the path of child indices (3 bits per level, one 64-bit
@@ -120,6 +125,8 @@ MVRT_DI uint32_t andOr( uint32_t a, uint32_t m, uint32_t c ) // (a & m) | c  (v_
 	asm( "v_and_or_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( a ), "v"( m ), "v"( c ) );
 	return r;
 }
+typedef unsigned long long lmask;						   // one bit per lane, wave-uniform (an SGPR pair)
+#define LANE( m ) __builtin_amdgcn_inverse_ballot_w64( m ) // this lane's bit of a lane mask, as a branch / select condition
 typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
 typedef uint32_t u4v __attribute__( ( ext_vector_type( 4 ) ) );
 typedef __attribute__( ( address_space( 3 ) ) ) u4v LdsU4; // (u4v: clang vector, assignable across address spaces)
@@ -420,6 +427,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			}
 		}
 #endif
+#ifdef MVRT_CANDIDATE_STEP // the round's earlier step: one candidate child per iteration (kept for A/B; 3.5 % slower)
 		// ---------------- (2) traversal steps until enough lanes are idle again ----------------
 		// (a clean inner loop: the per-lane state stays in the same registers from one step to the next)
 		for( ;; )
@@ -549,5 +557,172 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
 		if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
 		}
+#else
+		// ---------------- (2) traversal steps until enough lanes are idle again ----------------
+		// NODE-VISIT step.  The reference examines the candidate children of a node one at a time (voxCommon.hpp:362-412); measured on
+		// a path-traced bunny that is 30.3 candidate tests per ray for 20.6 node visits and 14.7 descents, and 2.0 of the 5.5 pops lead
+		// to no further descent.  Here ONE step settles a whole visit: the order in which the ray leaves the octants of a node is a
+		// pure function of the three mid-plane times and the three exit times -- walk the events (time, axis) in lexicographic order
+		// (the reference's min + "x first, then y" tie rule) until the first exit event; every earlier mid-plane event of a not yet
+		// passed axis is a flip -- so the up to four candidates, their existence in the node's mask and the "behind the origin" test
+		// are evaluated side by side, the first valid one is entered, and the node is pushed only if a later VALID candidate exists.
+		// All of it is 1-bit logic: the compares produce 64-bit lane masks and the combinatorics run on the scalar unit.  The child
+		// mask of every lane lives bit-sliced in three SGPR pairs (+ a "first visit" mask) while the loop runs.
+		lmask cmX = __ballot( ( childMask & 1u ) != 0u ), cmY = __ballot( ( childMask & 2u ) != 0u ), cmZ = __ballot( ( childMask & 4u ) != 0u );
+		lmask mFirst = __ballot( ( childMask & 8u ) != 0u );
+		for( ;; )
+		{
+			const lmask act = __ballot( st == 1u );
+			const float scale = mvrt_u2f( ( 127u - level ) << 23 );
+			const v2f t1yz = { ty1, tz1 };
+			const v2f dtyz = { dty, dtz };
+			const float tx0 = tx1 - dtx * scale; // :317-320
+			const v2f t0yz = t1yz - dtyz * scale;
+			const float ty0 = t0yz.x, tz0 = t0yz.y;
+			const float S = fmaxf( fmaxf( tx0, ty0 ), tz0 );
+			const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
+			const v2f tMyz = ( t0yz + t1yz ) * 0.5f;
+			const float tyM = tMyz.x, tzM = tMyz.y;
+			// octant the node is entered in (:342-348), or the candidate a popped node resumes with
+			const lmask X = ( mFirst & __ballot( txM < S ) ) | ( ~mFirst & cmX );
+			const lmask Y = ( mFirst & __ballot( tyM < S ) ) | ( ~mFirst & cmY );
+			const lmask Z = ( mFirst & __ballot( tzM < S ) ) | ( ~mFirst & cmZ );
+			// first exit event = lexicographic minimum of (t1, axis); flips = mid-plane events of unset axes that come before it
+			const float T = fminf( fminf( tx1, ty1 ), tz1 );
+			const lmask eX = __ballot( T == tx1 ), eY = __ballot( T == ty1 );
+			const lmask fX = ~X & __ballot( txM <= T );
+			const lmask fY = ~Y & ( __ballot( tyM < T ) | ( __ballot( tyM == T ) & ~eX ) );
+			const lmask fZ = ~Z & ( __ballot( tzM < T ) | ( __ballot( tzM == T ) & ~eX & ~eY ) );
+			// order of the flips among themselves: (tM, axis) lexicographic
+			const lmask xy = __ballot( txM <= tyM ), xz = __ballot( txM <= tzM ), yz = __ballot( tyM <= tzM );
+			const lmask yBx = fY & ~xy, zBx = fZ & ~xz; // y / z flips before x
+			const lmask xBy = fX & xy, zBy = fZ & ~yz;
+			const lmask xBz = fX & xz, yBz = fY & yz;
+			const lmask rX0 = fX & ~yBx & ~zBx, rX2 = fX & yBx & zBx, rX1 = fX & ~rX0 & ~rX2; // x is the 1st / 3rd / 2nd flip
+			const lmask rY0 = fY & ~xBy & ~zBy, rY2 = fY & xBy & zBy, rY1 = fY & ~rY0 & ~rY2;
+			const lmask rZ0 = fZ & ~xBz & ~yBz, rZ2 = fZ & xBz & yBz, rZ1 = fZ & ~rZ0 & ~rZ2;
+			const lmask n1 = rX0 | rY0 | rZ0, n2 = rX1 | rY1 | rZ1, n3 = rX2 | rY2 | rZ2; // candidate 1 / 2 / 3 exists geometrically
+			// child indices of the four candidates (mirrored space), nested: each adds the axis of one flip
+			const uint32_t i0 = ( LANE( X ) ? 1u : 0u ) | ( LANE( Y ) ? 2u : 0u ) | ( LANE( Z ) ? 4u : 0u );
+			const uint32_t i1 = i0 | ( LANE( rX0 ) ? 1u : ( LANE( rY0 ) ? 2u : ( LANE( rZ0 ) ? 4u : 0u ) ) );
+			const uint32_t i2 = i1 | ( LANE( rX1 ) ? 1u : ( LANE( rY1 ) ? 2u : ( LANE( rZ1 ) ? 4u : 0u ) ) );
+			const uint32_t i3 = i2 | ( LANE( rX2 ) ? 1u : ( LANE( rY2 ) ? 2u : ( LANE( rZ2 ) ? 4u : 0u ) ) );
+#define MVRT_EXISTS( i ) __ballot( EMBED ? bitMask( node, ( i ) ^ vMaskHi ) != 0u : ( ( nodeMask >> ( ( ( i ) ^ vMaskHi ) & 7u ) ) & 1u ) != 0u )
+			const lmask e0 = MVRT_EXISTS( i0 ), e1 = MVRT_EXISTS( i1 ), e2 = MVRT_EXISTS( i2 ), e3 = MVRT_EXISTS( i3 );
+#undef MVRT_EXISTS
+			// a candidate is behind the origin when the event that ends it is negative (:373).  Events are visited in time order, so the
+			// candidates behind the origin are a prefix: candidate k is behind iff more than k flips are negative, all of them iff the
+			// exit is
+			const lmask kx = fX & __ballot( txM < 0.0f ), ky = fY & __ballot( tyM < 0.0f ), kz = fZ & __ballot( tzM < 0.0f );
+			const lmask b0 = kx | ky | kz, b1 = ( kx & ky ) | ( ( kx | ky ) & kz ), b2 = kx & ky & kz;
+			const lmask mLeaf = act & __ballot( node == MVRT_LEAF ); // :322
+			const lmask inner = act & ~mLeaf & ~__ballot( T < 0.0f );
+			// candidate 0 of a popped node is the child it was left through: already done
+			const lmask v0 = mFirst & e0 & ~b0, v1 = n1 & e1 & ~b1, v2 = n2 & e2 & ~b2, v3 = n3 & e3;
+			const lmask mGo = inner & ( v0 | v1 | v2 | v3 );
+			const lmask l3 = v3, l2 = v2 | l3, l1 = v1 | l2; // a valid candidate at or after 3 / 2 / 1
+			const lmask mPush = inner & ( ( v0 & l1 ) | ( ~v0 & ( ( v1 & l2 ) | ( ~v1 & v2 & l3 ) ) ) ); // only if a later VALID candidate exists
+			const lmask mHit = mLeaf & __ballot( 0.0f < S ); // :324
+			const lmask mPop = act & ~mHit & ~mGo;
+			// the entered candidate = the first valid one
+			uint32_t ci = LANE( v2 ) ? i2 : i3;
+			ci = LANE( v1 ) ? i1 : ci;
+			ci = LANE( v0 ) ? i0 : ci;
+			const uint32_t childBit = ci ^ vMaskHi; // :369 (+24)
+			const uint32_t childIndex = childBit & 7u;
+
+			uint4 popped = make_uint4( 0u, 0u, 0u, 0u );
+			uint32_t poppedMask = 0;
+			const lmask mPopOk = mPop & __ballot( pending != 0u ); // (lane masks are only ever computed at the top level: a value assigned
+																  // under a divergent branch stops being wave-uniform for the compiler)
+			if( LANE( mGo ) )
+			{
+				if( LANE( mPush ) ) // push (:377-380)
+				{
+					const uint32_t slot = level & ( MVRT_RING - 1 );
+					const uint32_t clash = inLds & ( MVRT_RING_CLASH << slot );
+					if( clash ) // the slot still holds a shallower pending entry: evict it to HBM
+					{
+						const uint32_t lc = __builtin_ctz( clash );
+						*(u4v*)( (char*)spill + ( ( lc << spillShift ) + spillOff ) ) = myRing[slot * 64];
+						if( !EMBED ) *(uint32_t*)( (char*)spillMask + ( ( lc << spillMaskShift ) + spillMaskOff ) ) = myRingMask[slot * 64];
+						inLds &= ~clash;
+					}
+					u4v e;
+					e.x = node;
+					// the sign bits of a saved node's exit times are free (entered with min >= 0): they carry the child the node is left through
+					e.y = lshlOr( ci, 31u, mvrt_f2u( tx1 ) );
+					e.z = bfi( 0x7FFFFFFFu, mvrt_f2u( ty1 ), ci << 30 );
+					e.w = bfi( 0x7FFFFFFFu, mvrt_f2u( tz1 ), ci << 29 );
+					myRing[slot * 64] = e;
+					if( !EMBED ) myRingMask[slot * 64] = nodeMask;
+					pending |= 1u << level;
+					inLds |= 1u << level;
+				}
+				if( EMBED )
+				{
+					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
+					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
+				}
+				else
+				{
+					const Node64* nd = nodes + node; // up to 2^32 nodes: 64-bit addressing
+					nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu; // the child's mask: same line as
+					node = nd->children[childIndex];												 // its pointer
+				}
+				descents++;
+				path = ( path << 3 ) | childIndex;
+				tx1 = mvrt_u2f( bfi( bitMask( ci, 0 ), mvrt_f2u( tx1 ), mvrt_f2u( txM ) ) ); // :382-386: upper half -> keep the exit time, else the mid-plane
+				ty1 = mvrt_u2f( bfi( bitMask( ci, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
+				tz1 = mvrt_u2f( bfi( bitMask( ci, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
+				level++;
+			}
+			if( LANE( mPop ) ) // :414-422
+			{
+				if( pending == 0 ) // miss
+				{
+					st = 2u;
+				}
+				else
+				{
+					const uint32_t L = 31u - __builtin_clz( pending );
+					const uint32_t bit = 1u << L;
+					u4v ev;
+					asm volatile( "ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"( ev ) : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ) : "memory" );
+					popped = make_uint4( ev.x, ev.y, ev.z, ev.w );
+					if( !EMBED ) poppedMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
+					if( !( inLds & bit ) ) // rare; the empty asm keeps this a real branch (otherwise: address select + one flat load)
+					{
+						asm volatile( "" ::: "memory" );
+						popped = *(const uint4*)( (const char*)spill + ( ( L << spillShift ) + spillOff ) );
+						if( !EMBED ) poppedMask = *(const uint32_t*)( (const char*)spillMask + ( ( L << spillMaskShift ) + spillMaskOff ) );
+					}
+					pending &= ~bit;
+					inLds &= ~bit;
+					path >>= 3u * ( level - L );
+					level = L;
+					node = popped.x;
+					if( !EMBED ) nodeMask = poppedMask;
+					tx1 = mvrt_u2f( popped.y & 0x7FFFFFFFu );
+					ty1 = mvrt_u2f( popped.z & 0x7FFFFFFFu );
+					tz1 = mvrt_u2f( popped.w & 0x7FFFFFFFu );
+				}
+			}
+			if( LANE( mHit ) ) // :324-334
+			{
+				resT = S;
+				resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
+				st = 2u;
+			}
+			// bit-sliced child mask of the lanes that popped = the sign bits of the restored exit times; a descent starts a first visit
+			cmX = ( cmX & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.y < 0 ) );
+			cmY = ( cmY & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.z < 0 ) );
+			cmZ = ( cmZ & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.w < 0 ) );
+			mFirst = ( mFirst & ~mPopOk ) | mGo;
+			const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
+			if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
+		}
+		childMask = LANE( mFirst ) ? 8u : ( ( LANE( cmX ) ? 1u : 0u ) | ( LANE( cmY ) ? 2u : 0u ) | ( LANE( cmZ ) ? 4u : 0u ) );
+#endif
 	}
 }
