@@ -127,6 +127,17 @@ MVRT_DI uint32_t andOr( uint32_t a, uint32_t m, uint32_t c ) // (a & m) | c  (v_
 }
 typedef unsigned long long lmask;						   // one bit per lane, wave-uniform (an SGPR pair)
 #define LANE( m ) __builtin_amdgcn_inverse_ballot_w64( m ) // this lane's bit of a lane mask, as a branch / select condition
+// lane selects on a lane mask held in an SGPR pair, one v_cndmask_b32 each, issued as asm: written as nested ?: on LANE( m ) the
+// compiler turns a chain of them into a chain of branches (~10 SIMD-cycles apiece).  The masks they read are produced by SALU
+// instructions (no VALU-writes-SGPR hazard for the assembler-invisible reader).
+MVRT_DI uint32_t selU( lmask m, uint32_t a, uint32_t b ) // lane bit set ? a : b
+{
+	uint32_t r;
+	asm( "v_cndmask_b32 %0, %1, %2, %3" : "=v"( r ) : "v"( b ), "v"( a ), "s"( m ) );
+	return r;
+}
+#define MVRT_SELKK( m, K1, K0 ) ( { uint32_t r_; asm( "v_cndmask_b32 %0, " #K0 ", " #K1 ", %1" : "=v"( r_ ) : "s"( m ) ); r_; } )	   // bit ? K1 : K0
+#define MVRT_SELK( m, K1, b ) ( { uint32_t r_; asm( "v_cndmask_b32 %0, %1, " #K1 ", %2" : "=v"( r_ ) : "v"( b ), "s"( m ) ); r_; } ) // bit ? K1 : b
 typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
 typedef uint32_t u4v __attribute__( ( ext_vector_type( 4 ) ) );
 typedef __attribute__( ( address_space( 3 ) ) ) u4v LdsU4; // (u4v: clang vector, assignable across address spaces)
@@ -603,10 +614,11 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const lmask rZ0 = fZ & ~xBz & ~yBz, rZ2 = fZ & xBz & yBz, rZ1 = fZ & ~rZ0 & ~rZ2;
 			const lmask n1 = rX0 | rY0 | rZ0, n2 = rX1 | rY1 | rZ1, n3 = rX2 | rY2 | rZ2; // candidate 1 / 2 / 3 exists geometrically
 			// child indices of the four candidates (mirrored space), nested: each adds the axis of one flip
-			const uint32_t i0 = ( LANE( X ) ? 1u : 0u ) | ( LANE( Y ) ? 2u : 0u ) | ( LANE( Z ) ? 4u : 0u );
-			const uint32_t i1 = i0 | ( LANE( rX0 ) ? 1u : ( LANE( rY0 ) ? 2u : ( LANE( rZ0 ) ? 4u : 0u ) ) );
-			const uint32_t i2 = i1 | ( LANE( rX1 ) ? 1u : ( LANE( rY1 ) ? 2u : ( LANE( rZ1 ) ? 4u : 0u ) ) );
-			const uint32_t i3 = i2 | ( LANE( rX2 ) ? 1u : ( LANE( rY2 ) ? 2u : ( LANE( rZ2 ) ? 4u : 0u ) ) );
+			// (selU = one v_cndmask on an SGPR mask; written as nested ?: the compiler turns these chains into three branches each)
+			const uint32_t i0 = MVRT_SELKK( X, 1, 0 ) | MVRT_SELKK( Y, 2, 0 ) | MVRT_SELKK( Z, 4, 0 );
+			const uint32_t i1 = i0 | MVRT_SELK( rX0, 1, MVRT_SELK( rY0, 2, MVRT_SELKK( rZ0, 4, 0 ) ) );
+			const uint32_t i2 = i1 | MVRT_SELK( rX1, 1, MVRT_SELK( rY1, 2, MVRT_SELKK( rZ1, 4, 0 ) ) );
+			const uint32_t i3 = i2 | MVRT_SELK( rX2, 1, MVRT_SELK( rY2, 2, MVRT_SELKK( rZ2, 4, 0 ) ) );
 #define MVRT_EXISTS( i ) __ballot( EMBED ? bitMask( node, ( i ) ^ vMaskHi ) != 0u : ( ( nodeMask >> ( ( ( i ) ^ vMaskHi ) & 7u ) ) & 1u ) != 0u )
 			const lmask e0 = MVRT_EXISTS( i0 ), e1 = MVRT_EXISTS( i1 ), e2 = MVRT_EXISTS( i2 ), e3 = MVRT_EXISTS( i3 );
 #undef MVRT_EXISTS
@@ -625,9 +637,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const lmask mHit = mLeaf & __ballot( 0.0f < S ); // :324
 			const lmask mPop = act & ~mHit & ~mGo;
 			// the entered candidate = the first valid one
-			uint32_t ci = LANE( v2 ) ? i2 : i3;
-			ci = LANE( v1 ) ? i1 : ci;
-			ci = LANE( v0 ) ? i0 : ci;
+			const uint32_t ci = selU( v0, i0, selU( v1, i1, selU( v2, i2, i3 ) ) );
 			const uint32_t childBit = ci ^ vMaskHi; // :369 (+24)
 			const uint32_t childIndex = childBit & 7u;
 
