@@ -687,13 +687,8 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				tz1 = mvrt_u2f( bfi( bitMask( ci, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
 				level++;
 			}
-			if( LANE( mPop ) ) // :414-422
+			if( LANE( mPopOk ) ) // :414-422 (a lane that has to pop with an empty stack has missed: handled with the hits below)
 			{
-				if( pending == 0 ) // miss
-				{
-					st = 2u;
-				}
-				else
 				{
 					const uint32_t L = 31u - __builtin_clz( pending );
 					const uint32_t bit = 1u << L;
@@ -718,11 +713,17 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					tz1 = mvrt_u2f( popped.w & 0x7FFFFFFFu );
 				}
 			}
-			if( LANE( mHit ) ) // :324-334
+			// hit (:324-334) or miss: the lane holds its result until the next refill.  Selects, not a branch: some lane finishes in
+			// almost every iteration of a 64-lane wave anyway
 			{
-				resT = S;
-				resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
-				st = 2u;
+				// (these two masks come straight from a v_cmp: on gfx940+ a VALU-written SGPR needs two wait states before a VALU
+				// reads it, and the compiler cannot see a reader inside asm -- hence the s_nop in the template)
+				uint32_t nm;
+				asm( "s_nop 1\n\tv_cndmask_b32 %0, 0, 2, %1" : "=v"( nm ) : "s"( __ballot( S == ty0 ) ) );
+				asm( "s_nop 1\n\tv_cndmask_b32 %0, %0, 1, %1" : "+v"( nm ) : "s"( __ballot( S == tx0 ) ) );
+				resT = mvrt_u2f( selU( mHit, mvrt_f2u( S ), mvrt_f2u( resT ) ) );
+				resN = (int)selU( mHit, nm, (uint32_t)resN );
+				st = MVRT_SELK( mHit | ( mPop & ~mPopOk ), 2, st );
 			}
 			// bit-sliced child mask of the lanes that popped = the sign bits of the restored exit times; a descent starts a first visit
 			cmX = ( cmX & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.y < 0 ) );
