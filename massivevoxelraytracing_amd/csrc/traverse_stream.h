@@ -645,6 +645,34 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			uint32_t poppedMask = 0;
 			const lmask mPopOk = mPop & __ballot( pending != 0u ); // (lane masks are only ever computed at the top level: a value assigned
 																  // under a divergent branch stops being wave-uniform for the compiler)
+			// (pop before descend: the two touch disjoint lanes, and the child-pointer load issued by the descent is then the last
+			// thing of the iteration -- its latency overlaps with the slab arithmetic of the next one instead of being waited for here)
+			if( LANE( mPopOk ) ) // :414-422 (a lane that has to pop with an empty stack has missed: handled with the hits below)
+			{
+				{
+					const uint32_t L = 31u - __builtin_clz( pending );
+					const uint32_t bit = 1u << L;
+					u4v ev;
+					asm volatile( "ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"( ev ) : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ) : "memory" );
+					popped = make_uint4( ev.x, ev.y, ev.z, ev.w );
+					if( !EMBED ) poppedMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
+					if( !( inLds & bit ) ) // rare; the empty asm keeps this a real branch (otherwise: address select + one flat load)
+					{
+						asm volatile( "" ::: "memory" );
+						popped = *(const uint4*)( (const char*)spill + ( ( L << spillShift ) + spillOff ) );
+						if( !EMBED ) poppedMask = *(const uint32_t*)( (const char*)spillMask + ( ( L << spillMaskShift ) + spillMaskOff ) );
+					}
+					pending &= ~bit;
+					inLds &= ~bit;
+					path >>= 3u * ( level - L );
+					level = L;
+					node = popped.x;
+					if( !EMBED ) nodeMask = poppedMask;
+					tx1 = mvrt_u2f( popped.y & 0x7FFFFFFFu );
+					ty1 = mvrt_u2f( popped.z & 0x7FFFFFFFu );
+					tz1 = mvrt_u2f( popped.w & 0x7FFFFFFFu );
+				}
+			}
 			if( LANE( mGo ) )
 			{
 				if( LANE( mPush ) ) // push (:377-380)
@@ -686,32 +714,6 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				ty1 = mvrt_u2f( bfi( bitMask( ci, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
 				tz1 = mvrt_u2f( bfi( bitMask( ci, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
 				level++;
-			}
-			if( LANE( mPopOk ) ) // :414-422 (a lane that has to pop with an empty stack has missed: handled with the hits below)
-			{
-				{
-					const uint32_t L = 31u - __builtin_clz( pending );
-					const uint32_t bit = 1u << L;
-					u4v ev;
-					asm volatile( "ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"( ev ) : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ) : "memory" );
-					popped = make_uint4( ev.x, ev.y, ev.z, ev.w );
-					if( !EMBED ) poppedMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
-					if( !( inLds & bit ) ) // rare; the empty asm keeps this a real branch (otherwise: address select + one flat load)
-					{
-						asm volatile( "" ::: "memory" );
-						popped = *(const uint4*)( (const char*)spill + ( ( L << spillShift ) + spillOff ) );
-						if( !EMBED ) poppedMask = *(const uint32_t*)( (const char*)spillMask + ( ( L << spillMaskShift ) + spillMaskOff ) );
-					}
-					pending &= ~bit;
-					inLds &= ~bit;
-					path >>= 3u * ( level - L );
-					level = L;
-					node = popped.x;
-					if( !EMBED ) nodeMask = poppedMask;
-					tx1 = mvrt_u2f( popped.y & 0x7FFFFFFFu );
-					ty1 = mvrt_u2f( popped.z & 0x7FFFFFFFu );
-					tz1 = mvrt_u2f( popped.w & 0x7FFFFFFFu );
-				}
 			}
 			// hit (:324-334) or miss: the lane holds its result until the next refill.  Selects, not a branch: some lane finishes in
 			// almost every iteration of a 64-lane wave anyway
