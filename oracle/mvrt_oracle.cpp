@@ -865,6 +865,7 @@ struct TraceStats
 // [0] rays, [1] candidate tests (inner-loop turns), [2] descents, [3] pushes, [4] pops, [5] pops that were followed by a descent
 // from the restored node before the next pop ("fruitful"), [6] leaf checks, [7] node visits (outer-loop turns on inner nodes)
 static std::atomic<uint64_t> g_events[8];
+static std::atomic<int> g_eventsOn{ 0 }; // off by default: 8 contended atomics per ray cost the 16-thread CPU baseline a factor of 3
 
 static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_t nodeIndex, StackElement* stack, float3 ro, float3 rd, const float3& lower,
 												const float3& upper, float* t, int* nMajor, uint32_t* vIndex, bool isShadowRay, bool embedded, TraceStats* stats )
@@ -1003,9 +1004,10 @@ static void octreeTraverse_EfficientParametric( const OctreeNode* nodes, uint32_
 		}
 		else break;
 	}
-	if( stats )
+	if( stats && g_eventsOn.load( std::memory_order_relaxed ) )
 		for( int k = 0; k < 8; k++ ) g_events[k].fetch_add( ev[k], std::memory_order_relaxed );
 }
+ORC_API void orc_trace_events_enable( int on ) { g_eventsOn.store( on ); }
 ORC_API void orc_trace_events( uint64_t out[8], int reset )
 {
 	for( int k = 0; k < 8; k++ )
