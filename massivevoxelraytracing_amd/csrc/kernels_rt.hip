@@ -1019,6 +1019,9 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 				static const int envDiv = getenv( "MVRT_TRACE_GRID_DIV" ) ? atoi( getenv( "MVRT_TRACE_GRID_DIV" ) ) : 0;
 				const int div = envDiv > 0 ? envDiv : frame.traceGridDiv;
 				if( div > 1 && g > nCUs * STREAM_WAVES_PER_CU / div ) g = nCUs * STREAM_WAVES_PER_CU / div;
+				// experiment knob: waves per CU of a full-grid traversal launch (32 = every slot the register budget allows and then some)
+				static const int wpc = getenv( "MVRT_TRACE_WAVES_PER_CU" ) ? atoi( getenv( "MVRT_TRACE_WAVES_PER_CU" ) ) : 0;
+				if( wpc > 0 && g > nCUs * wpc / ( div > 1 ? div : 1 ) ) g = nCUs * wpc / ( div > 1 ? div : 1 );
 			}
 			if( svo.embedded )
 				hipLaunchKernelGGL( kPtTraceStream<true>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
