@@ -1017,7 +1017,10 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 				// a pass that shares the GPU with a sibling pass on another stream takes only 1/div of the wave slots, so that the two
 				// really run side by side (a full persistent grid would hold every slot until its own tail)
 				static const int envDiv = getenv( "MVRT_TRACE_GRID_DIV" ) ? atoi( getenv( "MVRT_TRACE_GRID_DIV" ) ) : 0;
-				const int div = envDiv > 0 ? envDiv : frame.traceGridDiv;
+				// ... for its BIG launches only (the first bounces; live counts are on the device, so the stage stands in for them): a small
+				// launch finishes sooner the more lanes it may use, and is gone before it can be in the sibling's way
+				static const int divMaxStage = getenv( "MVRT_TRACE_DIV_MAX_STAGE" ) ? atoi( getenv( "MVRT_TRACE_DIV_MAX_STAGE" ) ) : 99;
+				const int div = stage > divMaxStage ? 1 : ( envDiv > 0 ? envDiv : frame.traceGridDiv );
 				if( div > 1 && g > nCUs * STREAM_WAVES_PER_CU / div ) g = nCUs * STREAM_WAVES_PER_CU / div;
 				// experiment knob: waves per CU of a full-grid traversal launch (32 = every slot the register budget allows and then some)
 				static const int wpc = getenv( "MVRT_TRACE_WAVES_PER_CU" ) ? atoi( getenv( "MVRT_TRACE_WAVES_PER_CU" ) ) : 0;
