@@ -1198,8 +1198,10 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 		{
 			unsigned long long u[4];
 			MVRT_HIP( hipMemcpy( u, pt->buf.stats + 8, sizeof( u ), hipMemcpyDeviceToHost ) );
-			fprintf( stderr, "[util] wave-iterations %llu active-lane-iterations %llu (%.1f%% of lane slots); after stream exhausted: %llu wave-iterations (%.1f%% of all), %.1f%% lane use\n", u[0], u[1],
-					 100.0 * u[1] / ( 64.0 * ( u[0] ? u[0] : 1 ) ), u[2], 100.0 * u[2] / ( u[0] ? u[0] : 1 ), 100.0 * u[3] / ( 64.0 * ( u[2] ? u[2] : 1 ) ) );
+			// u[0], u[1]: refill events and the lanes active right after them; u[2], u[3]: wave-iterations of the node-visit loop and
+			// the lanes active in them
+			fprintf( stderr, "[util] wave-iterations %llu, active-lane-iterations %llu (%.1f%% of lane slots); refill events %llu; rays %llu -> %.2f lane-iterations per ray\n", u[2], u[3],
+					 100.0 * u[3] / ( 64.0 * ( u[2] ? u[2] : 1 ) ), u[0], (unsigned long long)s[0], (double)u[3] / (double)( s[0] ? s[0] : 1 ) );
 		}
 	}
 	pt->prof.collect();

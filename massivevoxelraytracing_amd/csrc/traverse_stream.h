@@ -584,6 +584,13 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		for( ;; )
 		{
 			const lmask act = __ballot( st == 1u );
+#ifdef MVRT_UTIL_STATS
+			if( lane == 0 ) // per wave-ITERATION tallies (the block above counts refill events)
+			{
+				io.utilTailIters++;
+				io.utilTailActive += (unsigned long long)__popcll( act );
+			}
+#endif
 			const float scale = mvrt_u2f( ( 127u - level ) << 23 );
 			const v2f t1yz = { ty1, tz1 };
 			const v2f dtyz = { dty, dtz };
