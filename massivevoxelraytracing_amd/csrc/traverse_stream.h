@@ -640,7 +640,11 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const lmask v0 = mFirst & e0 & ~b0, v1 = n1 & e1 & ~b1, v2 = n2 & e2 & ~b2, v3 = n3 & e3;
 			const lmask mGo = inner & ( v0 | v1 | v2 | v3 );
 			const lmask l3 = v3, l2 = v2 | l3, l1 = v1 | l2; // a valid candidate at or after 3 / 2 / 1
+#ifndef MVRT_REFERENCE_PUSH
 			const lmask mPush = inner & ( ( v0 & l1 ) | ( ~v0 & ( ( v1 & l2 ) | ( ~v1 & v2 & l3 ) ) ) ); // only if a later VALID candidate exists
+#else
+			const lmask mPush = inner & ( ( v0 & n1 ) | ( ~v0 & ( ( v1 & n2 ) | ( ~v1 & v2 & n3 ) ) ) ); // A/B: the reference's rule (any later candidate)
+#endif
 			const lmask mHit = mLeaf & __ballot( 0.0f < S ); // :324
 			const lmask mPop = act & ~mHit & ~mGo;
 			// the entered candidate = the first valid one
