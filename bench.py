@@ -239,6 +239,9 @@ def main():
             "descents_per_ray": round((st["descents"] + st["shadowDescents"]) / max(st["rays"], 1), 2),
             "trace_share_of_step_time": round(trace_ms / max(st["totalKernelMs"], 1e-9), 3),
             "trace_kernel_mrays_per_s": round(st["rays"] / (trace_ms * 1e-3) / 1e6, 1),
+            "limiter": "instruction issue (VALU ~80-90 % busy + the CU's shared scalar ALU), not bytes: this octree is cache resident; the HBM-bound configuration is "
+                       "`bench.py --mode stress` (profiles/r01_bench_stress.json: 3.0 TB/s of random 64-byte node lines = 94 % of the chip's measured "
+                       "random-line ceiling, profiles/r01_gfx950_issue_and_gather_costs.txt)",
         }
 
     # ---- CPU baseline (rank 0, single GPU runs only): the oracle on a bounded band of the same frame ----
