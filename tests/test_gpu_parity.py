@@ -341,3 +341,38 @@ def test_split_small_passes_is_result_neutral(mv, O, bunny256_color, hdr):
         out.append((pt.read_framebuffer()[: w * h].copy(), pt.stats()["rays"]))
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
     assert out[0][0][:, 3].min() == 16 * iters
+
+
+def test_trace_tie_cases_bit_exact(mv, O, bunny256):
+    """rays that produce EXACT ties between mid-plane and exit times (diagonals through lattice points of the octree, dyadic
+    origins): the node-visit step orders events lexicographically by (time, axis) -- the reference's min + 'x first, then y' rule --
+    and every tie-break must agree with the oracle, descents included"""
+    sc = bunny256
+    svo = upload(mv, sc)
+    lo, hi = sc.bounds()
+    ext = np.float32(sc.dps * sc.grid_res)
+    rng = np.random.default_rng(3)
+    ros, rds = [], []
+    dirs = [(1, 1, 1), (1, 1, -1), (1, -1, 1), (-1, 1, 1), (1, 1, 0.5), (1, 0.5, 1), (0.5, 1, 1), (1, 0.5, 0.25), (2, 1, 1), (1, 2, -1), (-1, -1, -1), (1, -1, -0.5)]
+    for k in range(6000):
+        # a lattice point of the 256^3 grid (or a node corner of a coarser level) inside the volume, approached along a diagonal
+        lvl = int(rng.integers(1, 9))
+        cell = ext / np.float32(2 ** lvl)
+        p = lo + cell * rng.integers(0, 2 ** lvl + 1, size=3).astype(np.float32)
+        d = np.array(dirs[k % len(dirs)], np.float32)
+        s = np.float32(2 ** int(rng.integers(0, 3)))  # dyadic distance: origin coordinates stay exactly representable relative to the grid
+        ros.append((p - d * ext * s).astype(np.float32))
+        rds.append(d if k % 3 else d * np.float32(0.5))
+    # and the same directions from inside the volume (origin ON lattice planes: S == 0 / negative events)
+    for k in range(3000):
+        lvl = int(rng.integers(1, 9))
+        cell = ext / np.float32(2 ** lvl)
+        p = lo + cell * rng.integers(0, 2 ** lvl + 1, size=3).astype(np.float32)
+        ros.append(p.astype(np.float32))
+        rds.append(np.array(dirs[k % len(dirs)], np.float32))
+    ro, rd = np.array(ros, np.float32), np.array(rds, np.float32)
+    sh = (np.arange(len(ro)) % 2).astype(np.uint8)
+    want = sc.trace(ro, rd, sh, threads=8, want_descents=True)
+    got = svo.intersect(ro, rd, sh, want_descents=True)
+    assert_hits_equal(want, got)
+    assert (want["t"] != O.MAX_FLOAT).sum() > 500
