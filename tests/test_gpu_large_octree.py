@@ -124,3 +124,25 @@ def test_synthetic_octree_matches_documented_generator(mv, O, res, n, flags):
     sc = O.Scene(nodes_w, attrs_w, np.zeros(3, np.float32), np.float32(1.0 / res), res, he, embedded=embed)
     ro, rd = random_rays(sc, 50_000, res)
     assert_hits_equal(sc.trace(ro, rd, threads=8, want_descents=True), svo.intersect(ro, rd, want_descents=True))
+
+
+@pytest.mark.parametrize("res,n,flags", [(2, 1, 0), (2, 64, 3), (4, 1, 1), (4, 3, 2), (8, 20_000, 0), (8, 20_000, 3), (16, 2, 0)])
+def test_degenerate_octrees(mv, O, res, n, flags):
+    """one-level octrees, a single voxel, a completely full grid: the edges of the traversal (root children are leaves, every
+    candidate exists, almost none does), both flavours"""
+    svo = mv.IntersectorOctreeGPU()
+    svo.build_synthetic(res, n, seed=99, flags=flags)
+    morton_w, attrs_w, he = synthetic_reference(O, res, n, 99)
+    dag, embed = not (flags & 1), not (flags & 2)
+    nodes_w = O.build_octree(morton_w, res, dag=dag, embed=embed)
+    assert svo.info().numberOfVoxels == len(morton_w) and svo.info().numberOfNodes == len(nodes_w)
+    sc = O.Scene(nodes_w, attrs_w, np.zeros(3, np.float32), np.float32(1.0 / res), res, he, embedded=embed)
+    ro, rd = random_rays(sc, 30_000, 5 + res)
+    # plus lattice diagonals (exact ties) through the unit cube
+    k = 3000
+    p = (np.random.default_rng(res).integers(0, res + 1, size=(k, 3)) / np.float32(res)).astype(np.float32)
+    d = np.array([(1, 1, 1), (1, -1, 1), (-1, 1, 0.5), (0.5, 1, -1)], np.float32)[np.arange(k) % 4]
+    ro = np.concatenate([ro, (p - d * np.float32(2.0)).astype(np.float32), p])
+    rd = np.concatenate([rd, d, d])
+    sh = (np.arange(len(ro)) % 3 == 0).astype(np.uint8)
+    assert_hits_equal(sc.trace(ro, rd, sh, threads=8, want_descents=True), svo.intersect(ro, rd, sh, want_descents=True))
