@@ -613,19 +613,19 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const lmask fZ = ~Z & ( __ballot( tzM < T ) | ( __ballot( tzM == T ) & ~eX & ~eY ) );
 			// order of the flips among themselves: (tM, axis) lexicographic
 			const lmask xy = __ballot( txM <= tyM ), xz = __ballot( txM <= tzM ), yz = __ballot( tyM <= tzM );
-			const lmask yBx = fY & ~xy, zBx = fZ & ~xz; // y / z flips before x
-			const lmask xBy = fX & xy, zBy = fZ & ~yz;
-			const lmask xBz = fX & xz, yBz = fY & yz;
-			const lmask rX0 = fX & ~yBx & ~zBx, rX2 = fX & yBx & zBx, rX1 = fX & ~rX0 & ~rX2; // x is the 1st / 3rd / 2nd flip
-			const lmask rY0 = fY & ~xBy & ~zBy, rY2 = fY & xBy & zBy, rY1 = fY & ~rY0 & ~rY2;
-			const lmask rZ0 = fZ & ~xBz & ~yBz, rZ2 = fZ & xBz & yBz, rZ1 = fZ & ~rZ0 & ~rZ2;
-			const lmask n1 = rX0 | rY0 | rZ0, n2 = rX1 | rY1 | rZ1, n3 = rX2 | rY2 | rZ2; // candidate 1 / 2 / 3 exists geometrically
-			// child indices of the four candidates (mirrored space), nested: each adds the axis of one flip
-			// (selU = one v_cndmask on an SGPR mask; written as nested ?: the compiler turns these chains into three branches each)
+			const lmask n1 = fX | fY | fZ, n2 = ( fX & fY ) | ( fZ & ( fX | fY ) ), n3 = fX & fY & fZ; // a 2nd / 3rd / 4th candidate exists geometrically
+			// the axis of the FIRST flip, and -- only when all three axes flip -- of the LAST one
+			const lmask aX = fX & ~( fY & ~xy ) & ~( fZ & ~xz );
+			const lmask aY = fY & ~( fX & xy ) & ~( fZ & ~yz );
+			const lmask aZ = fZ & ~( fX & xz ) & ~( fY & yz );
+			const lmask zX = n3 & ~( xy | xz ), zY = n3 & xy & ~yz, zZ = n3 & xz & yz;
+			// child indices of the four candidates (mirrored space), nested: each adds the axis of one flip.  With two flips the third
+			// candidate is already the last (i2 == i3); with three, it is the last minus the last flip
+			// (asm selects = one v_cndmask on an SGPR mask; written as nested ?: the compiler turns these chains into branches)
 			const uint32_t i0 = MVRT_SELKK( X, 1, 0 ) | MVRT_SELKK( Y, 2, 0 ) | MVRT_SELKK( Z, 4, 0 );
-			const uint32_t i1 = i0 | MVRT_SELK( rX0, 1, MVRT_SELK( rY0, 2, MVRT_SELKK( rZ0, 4, 0 ) ) );
-			const uint32_t i2 = i1 | MVRT_SELK( rX1, 1, MVRT_SELK( rY1, 2, MVRT_SELKK( rZ1, 4, 0 ) ) );
-			const uint32_t i3 = i2 | MVRT_SELK( rX2, 1, MVRT_SELK( rY2, 2, MVRT_SELKK( rZ2, 4, 0 ) ) );
+			const uint32_t i3 = i0 | MVRT_SELKK( fX, 1, 0 ) | MVRT_SELKK( fY, 2, 0 ) | MVRT_SELKK( fZ, 4, 0 );
+			const uint32_t i1 = i0 | MVRT_SELK( aX, 1, MVRT_SELK( aY, 2, MVRT_SELKK( aZ, 4, 0 ) ) );
+			const uint32_t i2 = i3 ^ MVRT_SELK( zX, 1, MVRT_SELK( zY, 2, MVRT_SELKK( zZ, 4, 0 ) ) );
 #define MVRT_EXISTS( i ) __ballot( EMBED ? bitMask( node, ( i ) ^ vMaskHi ) != 0u : ( ( nodeMask >> ( ( ( i ) ^ vMaskHi ) & 7u ) ) & 1u ) != 0u )
 			const lmask e0 = MVRT_EXISTS( i0 ), e1 = MVRT_EXISTS( i1 ), e2 = MVRT_EXISTS( i2 ), e3 = MVRT_EXISTS( i3 );
 #undef MVRT_EXISTS
@@ -739,9 +739,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				st = MVRT_SELK( mHit | ( mPop & ~mPopOk ), 2, st );
 			}
 			// bit-sliced child mask of the lanes that popped = the sign bits of the restored exit times; a descent starts a first visit
-			cmX = ( cmX & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.y < 0 ) );
-			cmY = ( cmY & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.z < 0 ) );
-			cmZ = ( cmZ & ~mPopOk ) | ( mPopOk & __ballot( (int)popped.w < 0 ) );
+			// (`popped` is zero for the lanes that did not pop)
+			cmX = ( cmX & ~mPopOk ) | __ballot( (int)popped.y < 0 );
+			cmY = ( cmY & ~mPopOk ) | __ballot( (int)popped.z < 0 );
+			cmZ = ( cmZ & ~mPopOk ) | __ballot( (int)popped.w < 0 );
 			mFirst = ( mFirst & ~mPopOk ) | mGo;
 			const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
 			if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
