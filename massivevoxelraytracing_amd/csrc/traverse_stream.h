@@ -605,12 +605,13 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const lmask X = ( mFirst & __ballot( txM < S ) ) | ( ~mFirst & cmX );
 			const lmask Y = ( mFirst & __ballot( tyM < S ) ) | ( ~mFirst & cmY );
 			const lmask Z = ( mFirst & __ballot( tzM < S ) ) | ( ~mFirst & cmZ );
-			// first exit event = lexicographic minimum of (t1, axis); flips = mid-plane events of unset axes that come before it
+			// first exit event = lexicographic minimum of (t1, axis); flips = mid-plane events of unset axes that come before it, i.e.
+			// before EVERY exit event (an axis' own exit never precedes its mid-plane: tM <= t1).  (tM_a, a) < (t1_b, b) is "tM_a <= t1_b" for
+			// a < b and "tM_a < t1_b" for a > b
 			const float T = fminf( fminf( tx1, ty1 ), tz1 );
-			const lmask eX = __ballot( T == tx1 ), eY = __ballot( T == ty1 );
-			const lmask fX = ~X & __ballot( txM <= T );
-			const lmask fY = ~Y & ( __ballot( tyM < T ) | ( __ballot( tyM == T ) & ~eX ) );
-			const lmask fZ = ~Z & ( __ballot( tzM < T ) | ( __ballot( tzM == T ) & ~eX & ~eY ) );
+			const lmask fX = ~X & __ballot( txM <= fminf( ty1, tz1 ) );
+			const lmask fY = ~Y & __ballot( tyM < tx1 ) & __ballot( tyM <= tz1 );
+			const lmask fZ = ~Z & __ballot( tzM < fminf( tx1, ty1 ) );
 			// order of the flips among themselves: (tM, axis) lexicographic
 			const lmask xy = __ballot( txM <= tyM ), xz = __ballot( txM <= tzM ), yz = __ballot( tyM <= tzM );
 			const lmask n1 = fX | fY | fZ, n2 = ( fX & fY ) | ( fZ & ( fX | fY ) ), n3 = fX & fY & fZ; // a 2nd / 3rd / 4th candidate exists geometrically
