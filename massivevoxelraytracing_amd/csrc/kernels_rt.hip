@@ -580,11 +580,14 @@ __global__ void __launch_bounds__( TRACE_BLOCK ) kPtTrace( PtParams P, int stage
 // Opaque view of a kernarg pointer: the asm makes the value unknown to the optimiser at this point, so the ~25 array
 // pointers read through it are (re)loaded with scalar loads where they are used -- at refill time -- instead of being
 // hoisted out of the traversal loop, where they would occupy ~60 SGPRs and push the node pointer out of registers.
+// The table is written by the host before the launch and never by a kernel: it is read through the CONSTANT address space, so the
+// pointer fetches are scalar loads that the compiler may batch freely (as plain global loads each of them had to be re-fetched, and
+// waited for, after every result store that might alias the table: ~9 dependent memory round trips per refill instead of ~3).
 template <class T>
-MVRT_DI const T* opaquePtr( const T* p )
+MVRT_DI const __attribute__( ( address_space( 4 ) ) ) T* opaquePtr( const T* p )
 {
 	asm volatile( "" : "+s"( p ) );
-	return p;
+	return (const __attribute__( ( address_space( 4 ) ) ) T*)p;
 }
 
 struct PtIO
@@ -605,8 +608,8 @@ struct PtIO
 	}
 	MVRT_DI bool load( uint32_t r, f3* ro, f3* rd ) const
 	{
-		const PtBuffers& buf = *opaquePtr( table );
-		const PathSet& in = buf.set[setIdx];
+		const __attribute__( ( address_space( 4 ) ) ) PtBuffers& buf = *opaquePtr( table );
+		const __attribute__( ( address_space( 4 ) ) ) PathSet& in = buf.set[setIdx];
 		uint32_t i;
 		const int kind = kindOf( r, &i );
 		*ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
@@ -617,7 +620,7 @@ struct PtIO
 	}
 	MVRT_DI void store( uint32_t r, const StreamHit& h, bool )
 	{
-		const PtBuffers& buf = *opaquePtr( table );
+		const __attribute__( ( address_space( 4 ) ) ) PtBuffers& buf = *opaquePtr( table );
 		uint32_t i;
 		const int kind = kindOf( r, &i );
 		const bool isHit = h.t != MVRT_MAXF;
