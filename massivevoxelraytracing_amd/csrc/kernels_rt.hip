@@ -603,7 +603,7 @@ struct PtIO
 	MVRT_DI int kindOf( uint32_t r, uint32_t* i ) const
 	{
 		const uint32_t kindSlot = ( r >= n ? 1u : 0u ) + ( r >= 2u * n ? 1u : 0u );
-		*i = r - kindSlot * n;
+		*i = r - ( kindSlot == 0u ? 0u : ( kindSlot == 1u ? n : 2u * n ) ); // (no integer multiply: quarter rate)
 		return kindSlot == 0 ? 0 : ( kindSlot == 1 ? ( shadowKind ? 1 : 2 ) : 2 );
 	}
 	MVRT_DI bool load( uint32_t r, f3* ro, f3* rd ) const
