@@ -81,9 +81,13 @@ int mvrt_svo_build( mvrt_svo* svo, const float* verticesHost, const float* vcolo
 /* Same with options.  MVRT_BUILD_NO_DAG: every sibling group becomes a node (the reference with ENABLE_GPU_DAG off,
  * voxKernel.cu:322-334; node numbering = deterministic group order).  MVRT_BUILD_NO_EMBEDDED_MASK: child pointers stay
  * plain indices and a node's mask is read from the node (voxCommon.hpp:353-356); chosen automatically when the octree has
- * >= 0xFFFFFF nodes, the limit of the embedded form (IntersectorOctreeGPU.hpp:231). */
+ * >= 0xFFFFFF nodes, the limit of the embedded form (IntersectorOctreeGPU.hpp:231).  MVRT_BUILD_CONSERVATIVE: conservative
+ * voxelization -- every voxel a triangle touches -- instead of the six-separating one (VTContext's sixSeparating == false,
+ * voxelization.hpp:186-189,296-301; the reference's GPU build hard-codes six-separating, voxKernel.cu:68,109, its CPU demo has the
+ * switch, voxRT.cpp:107,389). */
 #define MVRT_BUILD_NO_DAG 1
 #define MVRT_BUILD_NO_EMBEDDED_MASK 2
+#define MVRT_BUILD_CONSERVATIVE 4
 int mvrt_svo_build_ex( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
 					   const float origin[3], float dps, int gridRes, int flags );
 /* Seeded synthetic octree for HBM-bound stress runs (BASELINE.json configs[4]): nRandomVoxels uniformly random cells of the

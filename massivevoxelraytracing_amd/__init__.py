@@ -230,6 +230,7 @@ class IntersectorOctreeGPU:
 
     BUILD_NO_DAG = 1
     BUILD_NO_EMBEDDED_MASK = 2
+    BUILD_CONSERVATIVE = 4
 
     def build_synthetic(self, gridRes, n_random_voxels, seed, origin=(0.0, 0.0, 0.0), dps=None, flags=0, stream=None):
         """seeded random-voxel octree built on the GPU (HBM-bound stress, mvrt_svo_build_synthetic)"""

@@ -79,10 +79,12 @@ struct VT
 	int lox, loy, hix, hiy, loz, hiz;
 	float dC[3][3], nX[3][3], nY[3][3];
 	float ox, oy, oz;
-	float kx, ky, cSix;
+	float kx, ky, cSix, cMax, cMin;
+	bool conservative; // voxelization.hpp's sixSeparating == false: every voxel the triangle touches (:186-189, :296-301)
 
-	MVRT_DI void init( f3 v0, f3 v1, f3 v2, f3 origin, float dps, int gridRes ) // :148-229
+	MVRT_DI void init( f3 v0, f3 v1, f3 v2, f3 origin, float dps, int gridRes, bool conservativeMode = false ) // :148-229
 	{
+		conservative = conservativeMode;
 		f3 e01 = v1 - v0;
 		f3 e12 = v2 - v1;
 		f3 n = cross3( e01, e12 );
@@ -121,9 +123,15 @@ struct VT
 				float nex = -ey * nSign, ney = ex * nSign;
 				nX[axis][edge] = nex;
 				nY[axis][edge] = ney;
-				// six-separating: dot(ne, dp*0.5 - a) + 0.5*dps*max(|ne.x|,|ne.y|)   (:188-192)
-				float hx = dps * 0.5f - ax[edge], hy = dps * 0.5f - ay[edge];
-				dC[axis][edge] = ( nex * hx + ney * hy ) + 0.5f * dps * smax( sabs( nex ), sabs( ney ) );
+				if( conservative ) // max(ne.x*dp.x, 0) + max(ne.y*dp.y, 0) - dot(ne, a)   (:186-189)
+				{
+					dC[axis][edge] = smax( nex * dps, 0.0f ) + smax( ney * dps, 0.0f ) - ( nex * ax[edge] + ney * ay[edge] );
+				}
+				else // six-separating: dot(ne, dp*0.5 - a) + 0.5*dps*max(|ne.x|,|ne.y|)   (:190-193)
+				{
+					float hx = dps * 0.5f - ax[edge], hy = dps * 0.5f - ay[edge];
+					dC[axis][edge] = ( nex * hx + ney * hy ) + 0.5f * dps * smax( sabs( nex ), sabs( ney ) );
+				}
 			}
 		}
 		proj2( origin, major, &ox, &oy );
@@ -137,6 +145,8 @@ struct VT
 		kx = -nx / nz;
 		ky = -ny / nz;
 		float K = -kx * v0x - ky * v0y + v0z;
+		cMax = K + dps * ( smax( kx, 0.0f ) + smax( ky, 0.0f ) ); // :225-227
+		cMin = K + dps * ( smin( kx, 0.0f ) + smin( ky, 0.0f ) );
 		cSix = K + 0.5f * dps * ( kx + ky );
 	}
 	MVRT_DI i2 yRange( int x, float dps ) const // :235-274
@@ -163,16 +173,26 @@ struct VT
 		upperY = upperY > hiy ? hiy : upperY;
 		return i2{ lowerY, upperY };
 	}
-	MVRT_DI i2 zRange( int x, int y, float dps ) const // :275-306, sixSeparating branch
+	MVRT_DI i2 zRange( int x, int y, float dps ) const // :275-306
 	{
 		float px = ox + dps * x, py = oy + dps * y;
 		float var = kx * px + ky * py;
-		float tsix = var + cSix;
-		float indexf = ( tsix - oz ) / dps;
-		float zf = floorf( indexf );
-		int z = (int)zf;
-		int zmin = indexf == zf ? z - 1 : z;
-		int zmax = z;
+		int zmin, zmax;
+		if( conservative ) // :296-301
+		{
+			float tmax = var + cMax, tmin = var + cMin;
+			zmin = (int)floorf( ( tmin - oz ) / dps );
+			zmax = (int)floorf( ( tmax - oz ) / dps );
+		}
+		else
+		{
+			float tsix = var + cSix;
+			float indexf = ( tsix - oz ) / dps;
+			float zf = floorf( indexf );
+			int z = (int)zf;
+			zmin = indexf == zf ? z - 1 : z;
+			zmax = z;
+		}
 		zmin = zmin < loz ? loz : zmin;
 		zmax = zmax > hiz ? hiz : zmax;
 		return i2{ zmin, zmax };
@@ -234,13 +254,13 @@ MVRT_DI f3 closestBary( f3 v0, f3 v1, f3 v2, f3 P )
 template <bool EMIT>
 __global__ void __launch_bounds__( 128 ) kVoxelize( const float* __restrict__ verts, const float* __restrict__ cols, const float* __restrict__ emis, uint32_t nTri,
 													 unsigned long long* counter, f3 origin, float dps, int gridRes, uint64_t* __restrict__ mortonOut,
-													 uint64_t* __restrict__ attrOut )
+													 uint64_t* __restrict__ attrOut, int conservative )
 {
 	uint32_t iTri = blockIdx.x * blockDim.x + threadIdx.x;
 	if( iTri >= nTri ) return;
 	f3 v0 = loadV( verts, (uint64_t)iTri * 3 ), v1 = loadV( verts, (uint64_t)iTri * 3 + 1 ), v2 = loadV( verts, (uint64_t)iTri * 3 + 2 );
 	VT c;
-	c.init( v0, v1, v2, origin, dps, gridRes );
+	c.init( v0, v1, v2, origin, dps, gridRes, conservative != 0 );
 	uint32_t nVoxels = 0;
 	for( int x = c.lox; x <= c.hix; x++ )
 	{
@@ -727,7 +747,7 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 	// ---- voxelize: count, allocate, emit (IntersectorOctreeGPU.hpp:81-116) ----
 	const uint32_t triGrid = divUp( nTri, 128 );
 	hipLaunchKernelGGL( kVoxelize<false>, dim3( triGrid ), dim3( 128 ), 0, st, dVerts.as<float>(), (const float*)nullptr, (const float*)nullptr, nTri, counter, origin, dps,
-						gridRes, (uint64_t*)nullptr, (uint64_t*)nullptr );
+						gridRes, (uint64_t*)nullptr, (uint64_t*)nullptr, ( flags & 4 ) ? 1 : 0 );
 	unsigned long long totalDumped = 0;
 	MVRT_HIP( hipMemcpyAsync( &totalDumped, counter, 8, hipMemcpyDeviceToHost, st ) );
 	MVRT_HIP( hipStreamSynchronize( st ) );
@@ -745,7 +765,7 @@ int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const 
 	if( keysA.alloc( totalDumped * 8 ) || valsA.alloc( totalDumped * 8 ) ) return 1;
 	MVRT_HIP( hipMemsetAsync( counter, 0, 8, st ) );
 	hipLaunchKernelGGL( kVoxelize<true>, dim3( triGrid ), dim3( 128 ), 0, st, dVerts.as<float>(), dCols.as<float>(), dEmis.as<float>(), nTri, counter, origin, dps, gridRes,
-						keysA.as<uint64_t>(), valsA.as<uint64_t>() );
+						keysA.as<uint64_t>(), valsA.as<uint64_t>(), ( flags & 4 ) ? 1 : 0 );
 
 	dVerts.release();
 	dCols.release();

@@ -126,3 +126,28 @@ def test_update_scene_then_step_matches_oracle(mv, O):
     want, _, _ = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, 1), cam, w, h, 0, math_mode=1, threads=8)
     assert np.array_equal(pt.read_framebuffer()[: w * h], want)
     assert pt.getNumberOfVoxels() == len(sc.morton) and pt.getOctreeBytes() == len(sc.nodes) * 68
+
+
+@pytest.mark.parametrize("res", [64, 256])
+def test_conservative_voxelization_mode(mv, O, res):
+    """MVRT_BUILD_CONSERVATIVE = VTContext's sixSeparating == false (voxelization.hpp:186-189,296-301): every voxel a triangle
+    touches.  Voxel list, attributes and node array equal the oracle's conservative build; it is a superset of the six-separating one."""
+    from massivevoxelraytracing_amd import scenes
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    v = tris.reshape(-1, 3)
+    origin, dps = scenes.bounding_grid(v, res)
+    svo = mv.IntersectorOctreeGPU()
+    svo.build(v, cols.reshape(-1, 3), emis.reshape(-1, 3), None, origin, dps, res, flags=svo.BUILD_CONSERVATIVE)
+    morton_d, attrs_d = O.voxelize(tris, origin, dps, res, cols, emis, six_separating=False)
+    morton_w, attrs_w, he = O.merge_voxels(morton_d, attrs_d)
+    nodes_w = O.build_octree(morton_w, res, dag=True, embed=True)
+    info = svo.info()
+    assert info.totalDumpedVoxels == len(morton_d) and info.numberOfVoxels == len(morton_w) and info.numberOfNodes == len(nodes_w)
+    nodes, attrs, morton = svo.download(want_morton=True)
+    assert np.array_equal(morton, morton_w) and np.array_equal(attrs, attrs_w)
+    got = nodes.view(O.NODE_DTYPE)
+    for f in ("mask", "children", "psum"):
+        assert np.array_equal(got[f], nodes_w[f]), f
+    six = O.build_scene_from_triangles(tris, res, cols, emis)
+    assert len(morton_w) > len(six.morton) and np.isin(six.morton, morton_w).all()
