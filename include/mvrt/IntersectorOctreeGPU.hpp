@@ -54,14 +54,16 @@ struct IntersectorOctreeGPU
 	}
 
 	// reference :40-47 -- build(vertices, vcolors, vemissions, Shader*, stream, origin, dps, gridRes)
+	// (buildFlags: MVRT_BUILD_NO_DAG | MVRT_BUILD_NO_EMBEDDED_MASK | MVRT_BUILD_CONSERVATIVE -- the reference's compile-time switches
+	// ENABLE_GPU_DAG / ENABLE_EMBEDED_MASK, voxCommon.hpp:5-9, and VTContext's sixSeparating flag, as run-time options; 0 = the reference's defaults)
 	template <class V3>
 	void build( const std::vector<V3>& vertices, const std::vector<V3>& vcolors, const std::vector<V3>& vemissions, void* /*voxKernel*/, void* stream, V3 origin, float dps,
-				int gridRes )
+				int gridRes, int buildFlags = 0 )
 	{
 		static_assert( sizeof( V3 ) == 3 * sizeof( float ), "vertex type must be 3 packed floats" );
 		const float o[3] = { origin.x, origin.y, origin.z };
-		check( mvrt_svo_build( m_handle, reinterpret_cast<const float*>( vertices.data() ), vcolors.empty() ? nullptr : reinterpret_cast<const float*>( vcolors.data() ),
-							   vemissions.empty() ? nullptr : reinterpret_cast<const float*>( vemissions.data() ), vertices.size(), stream, o, dps, gridRes ),
+		check( mvrt_svo_build_ex( m_handle, reinterpret_cast<const float*>( vertices.data() ), vcolors.empty() ? nullptr : reinterpret_cast<const float*>( vcolors.data() ),
+								  vemissions.empty() ? nullptr : reinterpret_cast<const float*>( vemissions.data() ), vertices.size(), stream, o, dps, gridRes, buildFlags ),
 			   "IntersectorOctreeGPU::build" );
 		refresh();
 	}
