@@ -146,3 +146,39 @@ def test_degenerate_octrees(mv, O, res, n, flags):
     rd = np.concatenate([rd, d, d])
     sh = (np.arange(len(ro)) % 3 == 0).astype(np.uint8)
     assert_hits_equal(sc.trace(ro, rd, sh, threads=8, want_descents=True), svo.intersect(ro, rd, sh, want_descents=True))
+
+
+def test_hbm_sized_octree_properties(mv, O):
+    """A non-DAG octree beyond the embedded-mask limit (> 2^24 nodes: plain 32-bit child indices, 64-bit node addressing, child masks in
+    the parent's line) -- too big for the oracle, so checked through properties that do not need it: run-to-run determinism, the hit
+    point lies on a face of the voxel grid perpendicular to nMajor and in front of the origin, every hit has walked all levels, shadow
+    and normal rays agree on hit/miss, and a ray that starts behind its first hit and points back hits the same voxel plane."""
+    res, n_vox, n_rays = 2048, 40_000_000, 400_000
+    svo = mv.IntersectorOctreeGPU()
+    svo.build_synthetic(res, n_vox, seed=77, flags=svo.BUILD_NO_DAG)
+    info = svo.info()
+    assert info.numberOfNodes >= 0xFFFFFF and info.embeddedMask == 0 and info.levels == 11
+    assert 0.98 * n_vox < info.numberOfVoxels <= n_vox
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ro = (0.5 + 1.2 * d).astype(np.float32)
+    rd = (rng.random((n_rays, 3), dtype=np.float32) - ro).astype(np.float32)
+    a = svo.intersect(ro, rd, want_descents=True)
+    b = svo.intersect(ro, rd, want_descents=True)
+    for k in ("t", "nMajor", "vIndex", "descents"):
+        assert np.array_equal(a[k], b[k]), k
+    hit = a["t"] != O.MAX_FLOAT
+    assert hit.sum() > 0.5 * n_rays                     # 40 M random voxels in 2048^3: almost every ray hits something
+    assert (a["t"][hit] > 0).all() and (a["vIndex"][hit] < info.numberOfVoxels).all()
+    assert (a["descents"][hit] >= info.levels).all()
+    # hit point on a grid plane perpendicular to the reported axis (nMajor 1:x 2:y 0:z)
+    p = ro[hit].astype(np.float64) + rd[hit].astype(np.float64) * a["t"][hit][:, None].astype(np.float64)
+    axis = np.array([2, 0, 1])[a["nMajor"][hit]]
+    c = p[np.arange(len(p)), axis] * res
+    assert np.abs(c - np.round(c)).max() < 2e-3
+    assert ((p > -1e-4) & (p < 1 + 1e-4)).all()
+    # shadow rays report the same hit/miss
+    s = svo.intersect(ro, rd, np.ones(n_rays, np.uint8))
+    assert np.array_equal(s["t"] != O.MAX_FLOAT, hit)
+    assert (s["vIndex"] == 0).all()
