@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak check (GPU box): random cameras / lens settings on the two procedural scenes and the bunny, GPU path tracer vs CPU oracle, bit for bit
-(frame buffer, ray and descent counts).   usage: tools/soak.py [n_cameras] [grid_res]"""
+(frame buffer, ray and descent counts).   usage: tools/soak.py [n_cameras] [grid_res] [build_flags: 1 no DAG, 2 no embedded masks, 4 conservative]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,7 @@ from massivevoxelraytracing_amd import scenes
 
 n_cam = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rgba, hw, hh = O.decode_rgbe(hdr_bytes())
 H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
 rng = np.random.default_rng(2026)
@@ -28,11 +29,11 @@ for name, v, c, e in scene_list():
     sc = None
     pt = mv.PathTracer(); pt.setup(None); pt.resizeFrameBufferIfNeeded(None, W, Hh)
     pt.loadHDRIPixels(None, rgba, hw, hh, rgba, hw, hh)
-    pt.updateScene(v, c, e, None, origin, dps, res)
+    pt.m_intersectorOctreeGPU.build(v, c, e, None, origin, dps, res, flags=flags)
     if sc is None:  # oracle scene from the GPU-built octree (its builder is parity-tested separately)
         nodes, attrs, _ = pt.m_intersectorOctreeGPU.download()
         info = pt.m_intersectorOctreeGPU.info()
-        sc = O.Scene(nodes.view(O.NODE_DTYPE), attrs, origin, dps, res, info.hasEmission)
+        sc = O.Scene(nodes.view(O.NODE_DTYPE), attrs, origin, dps, res, info.hasEmission, embedded=bool(info.embeddedMask))
     lo, hi = sc.bounds(); centre = (lo + hi) / 2; ext = float((hi - lo).max())
     for k in range(n_cam):
         d = rng.normal(size=3); d /= np.linalg.norm(d)
