@@ -103,6 +103,11 @@ int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_t numberOfNo
 					 float dps, int gridRes, int hasEmission, int embeddedMask, void* stream );
 int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info );
 int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale ); /* m_emissionScale (:273) */
+/* m_nodeBuffer / m_vAttributeBuffer (:265-266): the device arrays.  Attributes are the reference's VoxelAttirb[numberOfVoxels]; nodes are
+ * this library's 64-byte lines {u32 children[8]; u32 nVoxelsPSum[8]} (the reference's 68-byte node minus its leading mask word, which rides
+ * in bits 24-31 of the parent's pointer) -- use mvrt_svo_download for the reference layout. */
+const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo );
+const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo );
 /* read the SVO back in the reference layout (parity checks of build); either pointer may be NULL */
 int mvrt_svo_download( const mvrt_svo* svo, void* nodes68Host, void* attribs8Host, uint64_t* mortonHost, void* stream );
 
@@ -138,6 +143,8 @@ int mvrt_pt_destroy( mvrt_pt* pt );				/* PathTracer::cleanUp, PathTracer.hpp:71
 /* PathTracer::setup (:43-69): PMJ02 table (pmjSampler.hpp:114-144) and work buffers.  The reference's kernel
  * path / include dir / isNvidia arguments have no meaning here (no runtime compilation). */
 int mvrt_pt_setup( mvrt_pt* pt, void* stream );
+/* read back PMJSampler::m_samples (pmjSampler.hpp:114-144): 128 sequences x 4096 float2 = 4 MiB */
+int mvrt_pt_download_pmj( mvrt_pt* pt, float* tableHost );
 int mvrt_pt_resize_framebuffer_if_needed( mvrt_pt* pt, void* stream, int width, int height ); /* :81-97 */
 int mvrt_pt_clear_framebuffer( mvrt_pt* pt, void* stream );									 /* :98-102, steps = 0 */
 /* PathTracer::loadHDRI (:104-116) + HDRI::load/loadPrimary (renderCommon.hpp:214-326): decoded float4 pixels.
@@ -146,6 +153,9 @@ int mvrt_pt_clear_framebuffer( mvrt_pt* pt, void* stream );									 /* :98-102,
 int mvrt_pt_load_hdri( mvrt_pt* pt, void* stream, const float* rgbaHost, int width, int height, const float* rgbaPrimaryHost, int widthPrimary, int heightPrimary );
 /* same from Radiance .hdr files (RGBE, flat or RLE; value = c * 2^(E-136)); filePrimary may be NULL */
 int mvrt_pt_load_hdri_file( mvrt_pt* pt, void* stream, const char* file, const char* filePrimary );
+/* host-only: decode a Radiance .hdr file to float4 pixels (alpha 1) exactly as mvrt_pt_load_hdri_file does -- flat and new-RLE scanlines,
+ * value = c * 2^(E-136).  rgbaHost may be NULL to query the size. */
+int mvrt_rgbe_read_file( const char* file, float* rgbaHost, uint64_t capacityPixels, int* width, int* height );
 /* read back one importance table (parity checks): which = 0 uniform, 1..6 = +x,-x,+y,-y,+z,-z; width*height u32 */
 int mvrt_pt_download_hdri_sat( mvrt_pt* pt, int which, uint32_t* satHost );
 int mvrt_pt_set_hdri_scale( mvrt_pt* pt, float scale ); /* HDRI::m_scale = 1.75 (renderCommon.hpp:480); <= 0 disables NEE */
@@ -198,6 +208,12 @@ int mvrt_resolve_buffer( const float* rgbaF32Dev, uint64_t nPixels, uint8_t* rgb
 const float* mvrt_pt_sample_radiance_dev( mvrt_pt* pt );
 /* host copy of the x, y, z planes (nSamples floats each) of the last pass; sample = (step * pixels + pixel) * 16 + spp */
 int mvrt_pt_read_sample_radiance( mvrt_pt* pt, float* xyzHost, uint64_t nSamples );
+
+/* Debug capture (parity of the live-path compaction, StreamCompaction.hpp:87-184 semantics): when enabled, every shade stage of a pass also
+ * keeps a copy of the survivor list it wrote.  read_debug_stage returns, for the LAST pass, the sample ids ("tasks": ((step * pixels + pixel)
+ * * 16 + spp)) of the paths that survived `stage` (0 = primary .. 7), in the order of their compacted slots: stable compaction <=> ascending. */
+int mvrt_pt_set_debug_capture( mvrt_pt* pt, int enabled );
+int mvrt_pt_read_debug_stage( mvrt_pt* pt, int stage, uint32_t* tasksHost, uint64_t capacity, uint32_t* survivorsOut );
 
 /* Counters and timings of the work since the last reset (all steps). */
 typedef struct mvrt_pt_stats

@@ -37,7 +37,7 @@ struct IntersectorOctreeGPU
 	explicit IntersectorOctreeGPU( mvrt_svo* borrowed ) : m_handle( borrowed ), m_owned( false ) {}
 	~IntersectorOctreeGPU()
 	{
-		if( m_owned ) mvrt_svo_destroy( m_handle );
+		if( m_owned && m_handle ) mvrt_svo_destroy( m_handle );
 	}
 	IntersectorOctreeGPU( const IntersectorOctreeGPU& ) = delete;
 	void operator=( const IntersectorOctreeGPU& ) = delete;
@@ -87,7 +87,18 @@ struct IntersectorOctreeGPU
 
 	mvrt_svo* handle() const { return m_handle; }
 
+	// re-bind to a handle owned by someone else (PathTracer::m_intersectorOctreeGPU is a VALUE member in the reference, PathTracer.hpp:18)
+	void attach( mvrt_svo* borrowed )
+	{
+		if( m_owned && m_handle ) mvrt_svo_destroy( m_handle );
+		m_handle = borrowed;
+		m_owned = false;
+		refresh();
+	}
+
 	// reference public members (:265-274), refreshed after build/upload
+	const void* m_vAttributeBuffer = nullptr; // device: VoxelAttirb[m_numberOfVoxels]
+	const void* m_nodeBuffer = nullptr;		  // device: 64-byte node lines (see mvrt.h; mvrt_svo_download gives the reference's 68-byte nodes)
 	uint32_t m_numberOfNodes = 0;
 	uint32_t m_numberOfVoxels = 0;
 	vec3 m_lower = { 0, 0, 0 };
@@ -99,7 +110,9 @@ struct IntersectorOctreeGPU
 	void refresh()
 	{
 		mvrt_svo_info i;
-		if( mvrt_svo_get_info( m_handle, &i ) != 0 ) return;
+		if( !m_handle || mvrt_svo_get_info( m_handle, &i ) != 0 ) return;
+		m_vAttributeBuffer = mvrt_svo_attribute_buffer_dev( m_handle );
+		m_nodeBuffer = mvrt_svo_node_buffer_dev( m_handle );
 		m_numberOfNodes = i.numberOfNodes;
 		m_numberOfVoxels = i.numberOfVoxels;
 		m_lower = { i.lower[0], i.lower[1], i.lower[2] };

@@ -22,7 +22,7 @@ namespace mvrt
 {
 struct PathTracer
 {
-	PathTracer() : m_intersectorOctreeGPU( nullptr ) {}
+	PathTracer() {}
 	~PathTracer() { cleanUp(); }
 	PathTracer( const PathTracer& ) = delete;
 	void operator=( const PathTracer& ) = delete;
@@ -37,14 +37,13 @@ struct PathTracer
 		if( !m_handle )
 		{
 			check( mvrt_pt_create( &m_handle ), "mvrt_pt_create" );
-			m_intersectorOctreeGPU = new IntersectorOctreeGPU( mvrt_pt_intersector( m_handle ) );
+			m_intersectorOctreeGPU.attach( mvrt_pt_intersector( m_handle ) );
 		}
 		check( mvrt_pt_setup( m_handle, stream ), "PathTracer::setup" );
 	}
 	void cleanUp() // :71-79
 	{
-		delete m_intersectorOctreeGPU;
-		m_intersectorOctreeGPU = nullptr;
+		m_intersectorOctreeGPU.attach( nullptr );
 		if( m_handle ) mvrt_pt_destroy( m_handle );
 		m_handle = nullptr;
 	}
@@ -65,7 +64,7 @@ struct PathTracer
 	template <class V3>
 	void updateScene( const std::vector<V3>& vertices, const std::vector<V3>& vcolors, const std::vector<V3>& vemissions, void* stream, V3 origin, float dps, int gridRes ) // :139-148
 	{
-		m_intersectorOctreeGPU->build( vertices, vcolors, vemissions, nullptr, stream, origin, dps, gridRes );
+		m_intersectorOctreeGPU.build( vertices, vcolors, vemissions, nullptr, stream, origin, dps, gridRes );
 	}
 	// :150-169; view/proj are the column-major 4x4 matrices GetCameraMatrix returns
 	void step( void* stream, const float view[16], const float proj[16], float focus, float lensR )
@@ -78,7 +77,7 @@ struct PathTracer
 
 	mvrt_pt* handle() const { return m_handle; }
 
-	IntersectorOctreeGPU* m_intersectorOctreeGPU; // reference member m_intersectorOctreeGPU (:18), owned by the handle
+	IntersectorOctreeGPU m_intersectorOctreeGPU; // reference member m_intersectorOctreeGPU (:18), a value as there; bound to the handle's octree by setup()
 	int m_width = 0;
 	int m_height = 0;
 

@@ -58,6 +58,9 @@ SIGNATURES = {
     "mvrt_svo_upload": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp, _f32, _i32, _i32, _i32, _vp]),
     "mvrt_svo_get_info": (_i32, [_vp, _vp]),
     "mvrt_svo_set_emission_scale": (_i32, [_vp, _f32]),
+    "mvrt_svo_node_buffer_dev": (_vp, [_vp]),
+    "mvrt_svo_attribute_buffer_dev": (_vp, [_vp]),
+    "mvrt_pt_download_pmj": (_i32, [_vp, _vp]),
     "mvrt_svo_download": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "mvrt_trace_batch": (_i32, [_vp, _u64] + [_vp] * 11 + [_vp]),
     "mvrt_trace_batch_host": (_i32, [_vp, _u64] + [_vp] * 7),
@@ -72,6 +75,7 @@ SIGNATURES = {
     "mvrt_pt_load_hdri": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32]),
     "mvrt_pt_load_hdri_file": (_i32, [_vp, _vp, C.c_char_p, C.c_char_p]),
     "mvrt_pt_download_hdri_sat": (_i32, [_vp, _i32, _vp]),
+    "mvrt_rgbe_read_file": (_i32, [C.c_char_p, _vp, _u64, _vp, _vp]),
     "mvrt_pt_set_hdri_scale": (_i32, [_vp, _f32]),
     "mvrt_pt_update_scene": (_i32, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _f32, _i32]),
     "mvrt_pt_intersector": (_vp, [_vp]),
@@ -95,6 +99,8 @@ SIGNATURES = {
     "mvrt_resolve_buffer": (_i32, [_vp, _u64, _vp, _vp]),
     "mvrt_pt_sample_radiance_dev": (_vp, [_vp]),
     "mvrt_pt_read_sample_radiance": (_i32, [_vp, _vp, _u64]),
+    "mvrt_pt_set_debug_capture": (_i32, [_vp, _i32]),
+    "mvrt_pt_read_debug_stage": (_i32, [_vp, _i32, _vp, _u64, _vp]),
     "mvrt_pt_set_profiling": (_i32, [_vp, _i32]),
     "mvrt_pt_reset_stats": (_i32, [_vp]),
     "mvrt_pt_get_stats": (_i32, [_vp, _vp, _vp]),
@@ -268,6 +274,8 @@ class IntersectorOctreeGPU:
     m_upper = property(lambda s: np.array(s.info().upper[:], np.float32))
     m_dps = property(lambda s: s.info().dps)
     m_hasEmission = property(lambda s: s.info().hasEmission)
+    m_nodeBuffer = property(lambda s: lib().mvrt_svo_node_buffer_dev(s._h))  # device pointers (:265-266)
+    m_vAttributeBuffer = property(lambda s: lib().mvrt_svo_attribute_buffer_dev(s._h))
 
     def hasEmission(self):
         return bool(self.info().hasEmission)
@@ -324,6 +332,15 @@ class IntersectorOctreeGPU:
         _check(lib().mvrt_render_primary(self._h, _hp(cam), width, height, int(showVertexColor), _dev_ptr(rgba_dev), None, None, None, None, stream))
 
 
+def read_rgbe_file(path):
+    """host-only: the .hdr decoder behind PathTracer.loadHDRI -> (rgba float32 (h*w, 4), w, h)"""
+    w, h = C.c_int(0), C.c_int(0)
+    _check(lib().mvrt_rgbe_read_file(path.encode(), None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((w.value * h.value, 4), np.float32)
+    _check(lib().mvrt_rgbe_read_file(path.encode(), _hp(out), len(out), C.byref(w), C.byref(h)))
+    return out, w.value, h.value
+
+
 def compact_indices(keep):
     """Stable compaction indices of host flags through the device path (StreamCompaction semantics)."""
     keep = np.ascontiguousarray(keep, np.uint8)
@@ -356,6 +373,12 @@ class PathTracer:
     def setup(self, stream=None, kernel=None, includeDir=None, isNvidia=False):
         """PathTracer::setup(stream, kernel, includeDir, isNvidia) (:43-69); the last three are ignored."""
         _check(lib().mvrt_pt_setup(self._h, stream))
+
+    def pmj_table(self):
+        """PMJSampler::m_samples as the host generated it (128 x 4096 float2)"""
+        out = np.zeros(2 * 4096 * 128, np.float32)
+        _check(lib().mvrt_pt_download_pmj(self._h, _hp(out)))
+        return out
 
     def set_tile(self, tile_index, tile_count):
         _check(lib().mvrt_pt_set_tile(self._h, tile_index, tile_count))
@@ -449,6 +472,17 @@ class PathTracer:
         out = np.zeros((3, n), np.float32)
         _check(lib().mvrt_pt_read_sample_radiance(self._h, _hp(out), n))
         return out.T.copy()
+
+    def set_debug_capture(self, on):
+        _check(lib().mvrt_pt_set_debug_capture(self._h, int(on)))
+
+    def debug_stage_survivors(self, stage, capacity=None):
+        """sample ids of the paths that survived shade stage `stage` of the last pass, in compacted-slot order (needs set_debug_capture)"""
+        cap = self.owned_pixels() * 16 * 8 if capacity is None else capacity
+        out = np.zeros(cap, np.uint32)
+        n = C.c_uint32(0)
+        _check(lib().mvrt_pt_read_debug_stage(self._h, stage, _hp(out), cap, C.byref(n)))
+        return out[: n.value].copy()
 
     def set_profiling(self, on):
         _check(lib().mvrt_pt_set_profiling(self._h, int(on)))

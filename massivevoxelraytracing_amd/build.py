@@ -21,12 +21,29 @@ FLAGS = [
 ] + os.environ.get("MVRT_EXTRA_FLAGS", "").split()
 
 
+STAMP = OUT + ".stamp"  # travels with the .so (git-ignored, not gpurun-ignored)
+
+
+def source_digest():
+    """SHA-256 over the flags and every source/header the library is compiled from: the binary that travels to the GPU box
+    is rebuilt whenever its sources differ from what it was built from -- file times say nothing after a checkout or a copy."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update("\0".join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp")))
+    deps += [os.path.join(HERE, "..", "include", f) for f in ("mvrt.h", "mvrt_detmath.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", f) for f in ("mvrt.h", "mvrt_detmath.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
 
 
 def build(force=False, verbose=True):
@@ -49,6 +66,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_digest())
     return OUT
 
 

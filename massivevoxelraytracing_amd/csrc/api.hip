@@ -142,6 +142,7 @@ struct mvrt_svo
 	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
 	mvrt_svo_info info;
 	uint8_t rootMask = 0;
+	mvrt_pt* owner = nullptr; // the PathTracer this is the m_intersectorOctreeGPU of (its deferred / in-flight steps read this octree)
 	mvrt_svo()
 	{
 		memset( &info, 0, sizeof( info ) );
@@ -206,6 +207,13 @@ struct mvrt_svo
 	}
 };
 
+// The reference's step() passes m_intersectorOctreeGPU and m_hdri to the kernel BY VALUE at call time (PathTracer.hpp:150-169).  step() is
+// deferred here, so every change of state a pending or in-flight step reads is preceded by launching (flush) or finishing (drain) those steps.
+static int ptFlush( mvrt_pt* pt );
+static int ptDrain( mvrt_pt* pt );
+static int ownerFlush( const mvrt_svo* s ) { return s && s->owner ? ptFlush( s->owner ) : 0; }
+static int ownerDrain( const mvrt_svo* s ) { return s && s->owner ? ptDrain( s->owner ) : 0; }
+
 static int ilog2Exact( int v )
 {
 	int l = 0;
@@ -247,6 +255,7 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
 	REQUIRE( !embeddedMask || numberOfNodes < 0xFFFFFFu, "embedded masks need fewer than 0xFFFFFF nodes (IntersectorOctreeGPU.hpp:231), got %u", numberOfNodes );
 	hipStream_t st = (hipStream_t)stream;
+	if( ownerDrain( svo ) ) return 1; // steps already issued keep the octree they were issued with
 	svo->cleanUp();
 	DevBuf raw;
 	if( raw.alloc( (uint64_t)numberOfNodes * 68 ) ) return 1;
@@ -290,6 +299,7 @@ MVRT_EXPORT int mvrt_svo_build_ex( mvrt_svo* svo, const float* verticesHost, con
 	REQUIRE( svo && verticesHost && nVertices >= 3 && nVertices % 3 == 0, "mvrt_svo_build: need 3*k vertices" );
 	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
 	hipStream_t st = (hipStream_t)stream;
+	if( ownerDrain( svo ) ) return 1; // steps already issued keep the octree they were issued with
 	svo->cleanUp(); // :53
 	SvoBuildResult r;
 	memset( &r, 0, sizeof( r ) );
@@ -305,6 +315,7 @@ MVRT_EXPORT int mvrt_svo_build_synthetic( mvrt_svo* svo, int gridRes, uint64_t n
 {
 	REQUIRE( svo, "null argument" );
 	REQUIRE( ilog2Exact( gridRes ) > 0 && gridRes <= ( 1 << 21 ), "gridRes %d is not a power of two in [2, 2^21]", gridRes );
+	if( ownerDrain( svo ) ) return 1;
 	svo->cleanUp();
 	SvoBuildResult r;
 	memset( &r, 0, sizeof( r ) );
@@ -318,9 +329,12 @@ MVRT_EXPORT int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info )
 	*info = svo->info;
 	return 0;
 }
+MVRT_EXPORT const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->nodes : nullptr; }
+MVRT_EXPORT const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->attrs : nullptr; }
 MVRT_EXPORT int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale )
 {
 	REQUIRE( svo, "null argument" );
+	if( ownerFlush( svo ) ) return 1; // pending steps are launched with the scale they were issued under
 	svo->info.emissionScale = scale;
 	return 0;
 }
@@ -649,7 +663,7 @@ struct mvrt_pt
 	// the frame-buffer additions stay in step order through an event chain.  depth 1 = everything on the caller's stream.
 	struct Slot
 	{
-		DevBuf work, wsBuf;
+		DevBuf work, wsBuf, dbg;
 		PtBuffers buf;
 		TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
 		hipStream_t stream = nullptr;
@@ -671,6 +685,7 @@ struct mvrt_pt
 	PtBuffers& buf = slots[0].buf; // slot 0 doubles as "the" buffer set for capacity / stats bookkeeping
 	bool setupDone = false;
 	bool profiling = false;
+	bool debugCapture = false; // keep the survivor list of every shade stage of the last pass (mvrt_pt_set_debug_capture)
 	EventProfiler prof;
 	int numCUs = 0;
 	mvrt_pt()
@@ -717,10 +732,12 @@ struct mvrt_pt
 	int drain() // host-side: everything the internal streams hold has finished
 	{
 		if( flush() ) return 1;
-		if( depth == 1 && pendingStream ) MVRT_HIP( hipStreamSynchronize( pendingStream ) );
+		// depth 1 runs on the caller's stream, which the caller may have destroyed since: wait for the event recorded behind the pass
+		if( lastAccum ) MVRT_HIP( hipEventSynchronize( lastAccum ) );
 		for( Slot& sl : slots )
 			if( sl.stream ) MVRT_HIP( hipStreamSynchronize( sl.stream ) );
 		pendingJoin = false;
+		pendingStream = nullptr;
 		return 0;
 	}
 	~mvrt_pt()
@@ -738,10 +755,14 @@ struct mvrt_pt
 	}
 };
 
+static int ptFlush( mvrt_pt* pt ) { return pt->flush(); }
+static int ptDrain( mvrt_pt* pt ) { return pt->drain(); }
+
 MVRT_EXPORT int mvrt_pt_create( mvrt_pt** out )
 {
 	mvrt_pt* pt = new mvrt_pt();
 	pt->intersector = new mvrt_svo();
+	pt->intersector->owner = pt;
 	*out = pt;
 	return 0;
 }
@@ -771,6 +792,13 @@ MVRT_EXPORT int mvrt_pt_setup( mvrt_pt* pt, void* stream )
 	MVRT_HIP( hipGetDeviceProperties( &p, dev ) );
 	pt->numCUs = p.multiProcessorCount;
 	pt->setupDone = true;
+	return 0;
+}
+
+MVRT_EXPORT int mvrt_pt_download_pmj( mvrt_pt* pt, float* tableHost )
+{
+	REQUIRE( pt && pt->pmj.p && tableHost, "mvrt_pt_download_pmj: call mvrt_pt_setup first" );
+	MVRT_HIP( hipMemcpy( tableHost, pt->pmj.p, pt->pmj.bytes, hipMemcpyDeviceToHost ) );
 	return 0;
 }
 
@@ -960,6 +988,17 @@ MVRT_EXPORT int mvrt_pt_load_hdri_file( mvrt_pt* pt, void* stream, const char* f
 	if( filePrimary && loadRgbe( filePrimary, b, &wp, &hp ) ) return 1;
 	return mvrt_pt_load_hdri( pt, stream, a.data(), w, h, filePrimary ? b.data() : nullptr, wp, hp );
 }
+// host-only: the decoder behind mvrt_pt_load_hdri_file (pr::Image2DRGBA32::loadFromHDR's role, PathTracer.hpp:106-113)
+MVRT_EXPORT int mvrt_rgbe_read_file( const char* file, float* rgbaHost, uint64_t capacityPixels, int* width, int* height )
+{
+	REQUIRE( file && width && height, "null argument" );
+	std::vector<float> a;
+	if( loadRgbe( file, a, width, height ) ) return 1;
+	if( !rgbaHost ) return 0;
+	REQUIRE( (uint64_t)*width * *height <= capacityPixels, "%s: %dx%d pixels do not fit %llu", file, *width, *height, (unsigned long long)capacityPixels );
+	memcpy( rgbaHost, a.data(), a.size() * sizeof( float ) );
+	return 0;
+}
 MVRT_EXPORT int mvrt_pt_download_hdri_sat( mvrt_pt* pt, int which, uint32_t* satHost )
 {
 	REQUIRE( pt && which >= 0 && which < 7 && pt->hdriSat[which].p, "no such HDRI table" );
@@ -969,6 +1008,7 @@ MVRT_EXPORT int mvrt_pt_download_hdri_sat( mvrt_pt* pt, int which, uint32_t* sat
 MVRT_EXPORT int mvrt_pt_set_hdri_scale( mvrt_pt* pt, float scale )
 {
 	REQUIRE( pt, "null argument" );
+	if( pt->flush() ) return 1; // pending steps are launched with the scale they were issued under (HDRI is a by-value kernel argument)
 	pt->hdri.scale = scale;
 	return 0;
 }
@@ -1055,6 +1095,12 @@ int mvrt_pt::launchPass( const CameraPinhole* passCams, int iteration, int nStep
 	pt->nextSlot = ( pt->nextSlot + 1 ) % pt->depth;
 	REQUIRE( sl.buf.cap >= pt->validOwnedPixels * MVRT_SPP_PER_STEP * f.nSteps, "internal: work buffers not allocated" );
 	if( ensureSlotWorkspace( pt, sl ) ) return 1;
+	sl.buf.dbgTasks = nullptr;
+	if( pt->debugCapture )
+	{
+		if( sl.dbg.bytes < sl.buf.cap * 4 * MVRT_MAX_DEPTH && sl.dbg.alloc( sl.buf.cap * 4 * MVRT_MAX_DEPTH ) ) return 1;
+		sl.buf.dbgTasks = sl.dbg.as<uint32_t>();
+	}
 	hipStream_t run = user;
 	hipEvent_t after = nullptr;
 	if( pt->depth > 1 )
@@ -1067,12 +1113,9 @@ int mvrt_pt::launchPass( const CameraPinhole* passCams, int iteration, int nStep
 	int rc = launchPtStep( pt->intersector->dev(), sl.ws, pt->hdri, pt->pmj.as<float2>(), cams, f, sl.buf, pt->fbF32.as<float4>(), pt->numCUs,
 						   pt->profiling ? &pt->prof : nullptr, run, after );
 	if( rc ) return rc;
-	if( pt->depth > 1 )
-	{
-		MVRT_HIP( hipEventRecord( sl.accumDone, run ) );
-		pt->lastAccum = sl.accumDone;
-		pt->pendingJoin = true;
-	}
+	MVRT_HIP( hipEventRecord( sl.accumDone, run ) );
+	pt->lastAccum = sl.accumDone;
+	if( pt->depth > 1 ) pt->pendingJoin = true;
 	return 0; // profiling events are collected lazily by mvrt_pt_get_stats (no sync inside step)
 }
 MVRT_EXPORT int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], const float proj[16], float focus, float lensR )
@@ -1160,6 +1203,27 @@ MVRT_EXPORT int mvrt_pt_assemble_tiles( const float* gatheredDev, int tileCount,
 MVRT_EXPORT int mvrt_resolve_buffer( const float* rgbaF32Dev, uint64_t nPixels, uint8_t* rgbaU8Dev, void* stream )
 {
 	return launchResolve( (const float4*)rgbaF32Dev, nPixels, (uchar4*)rgbaU8Dev, (hipStream_t)stream );
+}
+
+MVRT_EXPORT int mvrt_pt_set_debug_capture( mvrt_pt* pt, int enabled )
+{
+	REQUIRE( pt, "null argument" );
+	if( pt->drain() ) return 1;
+	pt->debugCapture = enabled != 0;
+	if( !enabled )
+		for( mvrt_pt::Slot& sl : pt->slots ) sl.dbg.release();
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_read_debug_stage( mvrt_pt* pt, int stage, uint32_t* tasksHost, uint64_t capacity, uint32_t* survivorsOut )
+{
+	REQUIRE( pt && stage >= 0 && stage < MVRT_MAX_DEPTH && survivorsOut, "bad arguments" );
+	if( pt->drain() ) return 1;
+	const mvrt_pt::Slot& sl = pt->slots[pt->lastSlot];
+	REQUIRE( sl.buf.dbgTasks, "debug capture was not enabled for the last pass" );
+	MVRT_HIP( hipMemcpy( survivorsOut, sl.buf.liveCount + stage + 1, 4, hipMemcpyDeviceToHost ) );
+	REQUIRE( *survivorsOut <= capacity && *survivorsOut <= sl.buf.cap, "tasksHost holds %llu entries, stage %d kept %u", (unsigned long long)capacity, stage, *survivorsOut );
+	if( tasksHost && *survivorsOut ) MVRT_HIP( hipMemcpy( tasksHost, sl.buf.dbgTasks + (uint64_t)stage * sl.buf.cap, (uint64_t)*survivorsOut * 4, hipMemcpyDeviceToHost ) );
+	return 0;
 }
 
 MVRT_EXPORT int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled )

@@ -1047,6 +1047,8 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		PROF_BEGIN( MVRT_K_SHADE );
 		hipLaunchKernelGGL( kPtShade, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
 		PROF_END();
+		if( buf.dbgTasks && stage < MVRT_MAX_DEPTH ) // debug capture: the compacted survivor list this stage wrote (parity of the compaction indices)
+			MVRT_HIP( hipMemcpyAsync( buf.dbgTasks + (uint64_t)stage * buf.cap, buf.set[setIdx ^ 1].task, nSamples * 4, hipMemcpyDeviceToDevice, stream ) );
 	}
 	// frame-buffer additions must happen in step order (fixed fp32 summation order): wait for the previous step's
 	if( accumulateAfter ) MVRT_HIP( hipStreamWaitEvent( stream, accumulateAfter, 0 ) );

@@ -32,6 +32,7 @@ struct PtBuffers
 	unsigned long long* cursors; // [16] per-stage ray cursors of the persistent traversal waves (zeroed by generate)
 	unsigned long long* stats; // [0] rays [1] shadowRays [2] descents [3] shadowDescents [4] hits [5] samples
 	uint64_t cap;
+	uint32_t* dbgTasks; // debug capture (host-side use only): [MVRT_MAX_DEPTH][cap] task ids of the survivors each shade stage wrote, in slot order
 	const PtBuffers* selfDev; // device-resident copy of this table (read with scalar loads where needed, see PtIO)
 };
 

@@ -1058,6 +1058,7 @@ ORC_API void* orc_scene_create( const uint8_t* nodes68, int64_t nNodes, const ui
 	return s;
 }
 ORC_API void orc_scene_destroy( void* s ) { delete (Scene*)s; }
+ORC_API void orc_scene_set_emission_scale( void* s, float scale ) { ( (Scene*)s )->emissionScale = scale; } // m_emissionScale, IntersectorOctreeGPU.hpp:273
 ORC_API void orc_scene_bounds( void* sp, float* lower3, float* upper3 )
 {
 	Scene* s = (Scene*)sp;
@@ -1619,7 +1620,7 @@ struct PTCounters
 
 // One sample of renderPT's task loop, voxKernel.cu:648-760.  Returns L.
 static float3 ptSample( const Scene& scene, const HDRI& hdri, const float* pmj, const CameraPinhole& pinhole, const Math& M, uint32_t pixelIdx, uint32_t spp, int W, int H,
-						StackElement* stack, PTCounters* cnt )
+						StackElement* stack, PTCounters* cnt, int* pathHits = nullptr )
 {
 	uint32_t x = pixelIdx % W;
 	uint32_t y = pixelIdx / W;
@@ -1647,6 +1648,7 @@ static float3 ptSample( const Scene& scene, const HDRI& hdri, const float* pmj, 
 	int nMajor = 0;
 	uint32_t vIndex = 0;
 	TRACE( ro, rd, &t, &nMajor, &vIndex, false );
+	int nPathHits = t != MAX_FLOAT ? 1 : 0; // consecutive hits of the path's own rays (primary, then one per bounce): how long the path stays alive
 	if( t == MAX_FLOAT ) // :678-689
 	{
 		float3 env = hdri.sampleNearest( rd, true );
@@ -1702,10 +1704,12 @@ static float3 ptSample( const Scene& scene, const HDRI& hdri, const float* pmj, 
 		TRACE( ro, rd, &t, &nMajor, &vIndex, false );
 		if( t != MAX_FLOAT )
 		{
+			nPathHits++;
 			float3 Le = scene.getVoxelEmission( vIndex, true );
 			L += T * Le * ( depth == 0 ? 1.0f / (float)( 1 + nSampleExtraDirect ) : 1.0f ); // :755
 		}
 	}
+	if( pathHits ) *pathHits = nPathHits;
 #undef SAMPLE_2D
 #undef TRACE
 	cnt->samples++;
@@ -1714,10 +1718,11 @@ static float3 ptSample( const Scene& scene, const HDRI& hdri, const float* pmj, 
 
 // fb: W*H float4, accumulated in place: xyz += sum over the 16 spp IN ASCENDING spp ORDER (the
 // reference's LDS atomicAdd order is nondeterministic, voxKernel.cu:763-765; ascending is the
-// order the HIP path fixes), w += 16 (:771-774).  pixelBegin/pixelEnd restrict the pixel range
+// order the HIP path fixes), w += 16 (:771-774).  samplePathHits (optional): how many of the path's own rays hit -- the wavefront
+// implementation keeps a path alive through exactly that many stages, so its stable compaction can be checked index by index.  pixelBegin/pixelEnd restrict the pixel range
 // (bounded CPU-baseline samples).  sampleL (optional): per-sample radiance, (pixel*16+s)*3.
 ORC_API void orc_render_pt( void* sp, void* hp, const float* pmjTable, const float* cam15, int W, int H, int iteration, int mathMode, float* fb, int64_t pixelBegin,
-							int64_t pixelEnd, float* sampleL, uint64_t* counters6, int nThreads )
+							int64_t pixelEnd, float* sampleL, uint64_t* counters6, int nThreads, uint8_t* samplePathHits /* optional, (pixel*16+s): 0..9 */ )
 {
 	const Scene& scene = *(Scene*)sp;
 	HDRI& hdri = *(HDRI*)hp;
@@ -1737,7 +1742,9 @@ ORC_API void orc_render_pt( void* sp, void* hp, const float* pmjTable, const flo
 			for( int s = 0; s < nBatchSpp; s++ )
 			{
 				uint32_t spp = iteration * nBatchSpp + s; // :642
-				float3 L = ptSample( scene, hdri, pmjTable, pinhole, M, (uint32_t)p, spp, W, H, stack, &cnts[k] );
+				int ph = 0;
+				float3 L = ptSample( scene, hdri, pmjTable, pinhole, M, (uint32_t)p, spp, W, H, stack, &cnts[k], &ph );
+				if( samplePathHits ) samplePathHits[( p - pixelBegin ) * nBatchSpp + s] = (uint8_t)ph;
 				acc.x += L.x;
 				acc.y += L.y;
 				acc.z += L.z;

@@ -68,6 +68,7 @@ _merge = _sig("orc_merge_voxels", _i64, [_vp, _vp, _i64, _vp])
 _build_octree = _sig("orc_build_octree", _i64, [_vp, _i64, _i32, _i32, _i32, _vp, _i64])
 _scene_create = _sig("orc_scene_create", _vp, [_vp, _i64, _vp, _i64, _vp, _f32, _i32, _i32, _i32])
 _scene_destroy = _sig("orc_scene_destroy", None, [_vp])
+_scene_set_emission_scale = _sig("orc_scene_set_emission_scale", None, [_vp, _f32])
 _scene_bounds = _sig("orc_scene_bounds", None, [_vp, _vp, _vp])
 _trace = _sig("orc_trace_batch", None, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32])
 _cam_mat = _sig("orc_camera_from_matrices", None, [_vp, _vp, _f32, _f32, _vp])
@@ -81,7 +82,7 @@ _hdri_is = _sig("orc_hdri_importance_sample", None, [_vp, _vp, _i32, _vp, _vp, _
 _hdri_near = _sig("orc_hdri_sample_nearest", None, [_vp, _vp, _i32, _vp])
 _rgbe = _sig("orc_decode_rgbe", _i32, [_vp, _i64, _vp, _vp, _vp, _i64])
 _render_primary = _sig("orc_render_primary", None, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32])
-_render_pt = _sig("orc_render_pt", None, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _i32])
+_render_pt = _sig("orc_render_pt", None, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp])
 _resolve = _sig("orc_resolve", None, [_vp, _i64, _i32, _vp])
 _compact = _sig("orc_compact_indices", _i64, [_vp, _i64, _vp, _vp])
 _detmath = _sig("orc_detmath_eval", None, [_i32, _vp, _vp, _i64, _vp])
@@ -212,6 +213,9 @@ class Scene:
             _scene_destroy(self._h)
             self._h = None
 
+    def set_emission_scale(self, s):
+        _scene_set_emission_scale(self._h, float(s))
+
     def bounds(self):
         lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
         _scene_bounds(self._h, _p(lo), _p(hi))
@@ -244,7 +248,8 @@ class Scene:
         _render_primary(self._h, _p(cam), W, H, int(show_vertex_color), _p(rgba), _p(t), _p(nm), _p(vi), _p(de), threads)
         return {"rgba": rgba, "t": t, "nMajor": nm, "vIndex": vi, "descents": de}
 
-    def render_pt(self, hdri, cam, W, H, iteration, math_mode=1, fb=None, pixel_begin=0, pixel_end=-1, want_samples=False, threads=1, pmj=None):
+    def render_pt(self, hdri, cam, W, H, iteration, math_mode=1, fb=None, pixel_begin=0, pixel_end=-1, want_samples=False, threads=1, pmj=None, path_hits=None):
+        """path_hits: optional uint8 array ((pixel_end - pixel_begin) * 16) that receives, per sample, how many of the path's own rays hit"""
         cam = np.ascontiguousarray(cam, np.float32)
         pmj = pmj_table() if pmj is None else pmj
         if fb is None:
@@ -252,7 +257,9 @@ class Scene:
         pe = W * H if pixel_end < 0 else pixel_end
         sl = np.zeros(((pe - pixel_begin) * 16, 3), np.float32) if want_samples else None
         cnt = np.zeros(6, np.uint64)
-        _render_pt(self._h, hdri._h, _p(pmj), _p(cam), W, H, iteration, math_mode, _p(fb), pixel_begin, pe, _p(sl), _p(cnt), threads)
+        if path_hits is not None:
+            assert path_hits.dtype == np.uint8 and path_hits.flags.c_contiguous and path_hits.size == (pe - pixel_begin) * 16
+        _render_pt(self._h, hdri._h, _p(pmj), _p(cam), W, H, iteration, math_mode, _p(fb), pixel_begin, pe, _p(sl), _p(cnt), threads, _p(path_hits))
         counters = dict(zip(["rays", "shadowRays", "descents", "shadowDescents", "hits", "samples"], (int(v) for v in cnt)))
         return fb, sl, counters
 

@@ -376,3 +376,72 @@ def test_trace_tie_cases_bit_exact(mv, O, bunny256):
     got = svo.intersect(ro, rd, sh, want_descents=True)
     assert_hits_equal(want, got)
     assert (want["t"] != O.MAX_FLOAT).sum() > 500
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_path_tracer_compaction_indices_bit_exact(mv, O, bunny256_color, hdr, batch):
+    """north_star: 'bit-exact for ... compaction indices'.  The path tracer's own compaction (survivor counts from the traversal's result
+    stores, scan, ballot rank in the shade kernel) must place the survivors of every stage exactly where StreamCompaction::filter
+    (StreamCompaction.hpp:87-184) would: slot j holds the j-th surviving sample in ascending sample order.  The oracle says how many of its
+    own rays each sample's path hit, i.e. through how many stages it survives."""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h = 150, 85  # W*H not a multiple of 256
+    cams = [probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.03, offset=(6 - 0.4 * i, 4, 6)) for i in range(batch)]
+    pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    pt.set_batch_steps(batch)
+    pt.set_debug_capture(True)
+    for c in cams:
+        pt.step(None, c)
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    hits = np.zeros((batch, w * h * 16), np.uint8)
+    for it, c in enumerate(cams):
+        sc.render_pt(H, c, w, h, it, math_mode=1, threads=8, path_hits=hits[it])
+    flat = hits.reshape(-1)  # sample id = (step * pixels + pixel) * 16 + spp
+    total = 0
+    for s in range(8):
+        got = pt.debug_stage_survivors(s, batch * w * h * 16)
+        assert np.array_equal(got, np.nonzero(flat > s)[0].astype(np.uint32)), s
+        total += len(got)
+    assert total > 0 and (flat > 1).any()
+
+
+def test_state_changes_between_deferred_steps(mv, O, bunny256_color, hdr):
+    """step() is deferred and batched inside the library, but the reference passes the HDRI and the intersector to the kernel BY VALUE at
+    call time (PathTracer.hpp:150-169): a step must render with the state it was issued under.  step; change the HDRI scale and the
+    emission scale; step; replace the scene; step -- against the oracle doing the same, and against an unbatched tracer."""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h = 96, 54
+    cam = probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.05)
+    plain = O.build_scene_from_triangles(bunny_tris(), 256)
+    results = []
+    for batch in (8, 1):
+        pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+        pt.set_batch_steps(batch)
+        pt.step(None, cam)                       # iteration 0: scale 1.75, emission 7.5
+        pt.set_hdri_scale(0.5)
+        pt.m_intersectorOctreeGPU.set_emission_scale(2.0)
+        pt.step(None, cam)                       # iteration 1: scale 0.5, emission 2
+        pt.m_intersectorOctreeGPU.upload(plain.nodes, plain.attrs, plain.origin, plain.dps, 256, plain.has_emission)
+        pt.step(None, cam)                       # iteration 2: white bunny without emission
+        results.append(pt.read_framebuffer()[: w * h].copy())
+    assert np.array_equal(results[0], results[1])
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb, _, _ = sc.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
+    H.set_scale(0.5)
+    sc.set_emission_scale(2.0)
+    fb, _, _ = sc.render_pt(H, cam, w, h, 1, math_mode=1, fb=fb, threads=8)
+    sc.set_emission_scale(7.5)
+    fb, _, _ = plain.render_pt(H, cam, w, h, 2, math_mode=1, fb=fb, threads=8)
+    assert np.array_equal(results[0], fb)
+
+
+def test_product_pmj_table_is_the_golden_table(mv):
+    """PMJSampler::setup (pmjSampler.hpp:114-144): the PRODUCT's table, read back from the device, has the SHA-256 the survey captured"""
+    import hashlib
+    pt = mv.PathTracer()
+    pt.setup(None)
+    t = pt.pmj_table()
+    assert t.nbytes == G["pmj_table_bytes"]
+    assert hashlib.sha256(t.tobytes()).hexdigest() == G["pmj_table_sha256"]
