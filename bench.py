@@ -12,10 +12,13 @@ RCCL all-gather and assembled into the full frame -- all inside the timed region
 
 Timed region: inputs resident in HBM (scene built, HDRI/PMJ tables uploaded, buffers allocated) before it
 starts; K steps (+ gather for N > 1) between barrier + device synchronize on both sides; max over ranks.
+The K steps are rendered as 64-spp FRAMES (4 steps each; the metric's unit of work): clear, 4 steps, gather, device synchronise -- so
+`value` is the 64-spp figure whatever K the driver asks for (longer runs do not amortise a frame's latency floor).
 
 The JSON line also carries
-  roofline     -- traversal kernel (kPtTrace): algorithmic bytes per launch / mean launch time, both measured
-                  in the timed region (HIP events on the launch stream), against the 8 TB/s HBM peak;
+  roofline     -- traversal kernel (kPtTraceStream): algorithmic bytes per launch / mean launch time, measured in an extra
+                  NON-OVERLAPPED pass after the timed region (pipeline depth 1, one step per pass: HIP events on the one stream
+                  every kernel runs on, so kernel times cannot overlap), against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (a port of the reference's voxRT / renderPT arithmetic, oracle/) timed on this
                   host's cores on a bounded band of the same frame (rank 0, N = 1 only).
 """
@@ -90,25 +93,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid-res", type=int, default=2048)
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "rtcamp"])
+    ap.add_argument("--grid-res", type=int, default=0, help="0 = the scene's BASELINE size (dragon 2048, rtcamp 4096, cave 2048)")
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "rtcamp", "cave"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--frame-steps", type=int, default=4, help="steps per frame: 4 = the metric's 64 spp.  The K timed steps are rendered as frames of this many steps, the "
+                    "frame buffer cleared and the device synchronised between frames, so `value` is the 64-spp figure whatever K is (0 = one frame of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra non-overlapped pass the roofline numbers come from")
+    ap.add_argument("--serial-only", action="store_true", help="run ONLY the non-overlapped pass (pipeline depth 1, batch 1): the command profiles/ *_serial_kernel_stats.csv is taken from")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--voxels", type=float, default=1e8, help="stress mode: random voxels of the synthetic octree")
-    ap.add_argument("--rays", type=float, default=6.4e7, help="stress mode: incoherent rays per step")
+    ap.add_argument("--voxels", type=float, default=6.5e8, help="stress mode: random voxels of the synthetic octree")
+    ap.add_argument("--rays", type=float, default=1.6e7, help="stress mode: incoherent rays per step")
     ap.add_argument("--mode", default="pt", choices=["pt", "primary", "stress"], help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2)")
     ap.add_argument("--emulate-tiles", type=int, default=0, help="diagnostic: render only tile 0 of N on one GPU (predicts per-rank time of an N-GPU run)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
+    if args.grid_res == 0:
+        args.grid_res = {"dragon": 2048, "rtcamp": 4096, "cave": 2048}[args.scene] if args.mode != "stress" else 8192
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch N > 1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`" % (args.gpus, world))
     dist = None
     torch = None
     force_dist = os.environ.get("MVRT_FORCE_DIST") == "1"
@@ -121,7 +130,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import massivevoxelraytracing_amd as mv
-    from massivevoxelraytracing_amd import scenes, tiles
+    from massivevoxelraytracing_amd import scenes
     mv.lib()
     mv.set_device(local_rank)
 
@@ -136,7 +145,7 @@ def main():
 
     # ---- scene + renderer (outside the timed region) ----
     t_setup = time.time()
-    verts, cols, emis = (scenes.dragon_standin if args.scene == "dragon" else scenes.rtcamp_standin)(args.detail)
+    verts, cols, emis = scenes.SCENES[args.scene](args.detail)
     origin, dps = scenes.bounding_grid(verts, args.grid_res)
     W, H = args.width, args.height
     pt = mv.PathTracer()
@@ -152,12 +161,11 @@ def main():
     info = pt.m_intersectorOctreeGPU.info()
     lo, hi = np.array(info.lower[:]), np.array(info.upper[:])
     centre = (lo + hi) / 2
-    if args.scene == "dragon":
-        eye = centre + np.array([2.6, 1.5, 3.1])
+    if args.scene == "cave":
+        cam = scenes.cave_camera(lo, hi)
     else:
-        eye = centre + np.array([4.2, 2.2, 5.0])
-    focus = float(np.linalg.norm(eye - centre))
-    cam = scenes.look_at_camera(eye, centre, 40.0, focus, 0.02)
+        eye = centre + (np.array([2.6, 1.5, 3.1]) if args.scene == "dragon" else np.array([4.2, 2.2, 5.0]))
+        cam = scenes.look_at_camera(eye, centre, 40.0, float(np.linalg.norm(eye - centre)), 0.02)
     setup_s = time.time() - t_setup
 
     if args.mode == "primary":
@@ -184,29 +192,60 @@ def main():
         gather_out = torch.empty(world * owned * 4, dtype=torch.float32, device="cuda")
         frame = torch.empty(W * H * 4, dtype=torch.float32, device="cuda")
 
-    def run_steps(k):
-        for _ in range(k):
-            pt.step(None, cam)
-        pt.join(None)  # step() is deferred/pipelined inside the library: launch and order everything behind the stream
-        if dist is not None:
-            mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16)
-            mv.synchronize()  # the copy ran on the null stream; RCCL uses torch's stream
-            dist.all_gather_into_tensor(gather_out, gather_in)
-            torch.cuda.current_stream().synchronize()
-            mv.assemble_tiles(gather_out, world, owned, W, H, frame)
+    frame_steps = args.frame_steps if args.frame_steps > 0 else max(args.steps, 1)
 
-    # ---- warmup, then the timed region ----
-    run_steps(args.warmup)
-    pt.clearFrameBuffer(None)
-    pt.reset_stats()
-    pt.set_profiling(True)
-    barrier_sync()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    st = pt.stats()
-    pt.set_profiling(False)
+    def run_steps(k):
+        """k steps as frames of `frame_steps` steps (64 spp): per frame clear -> steps -> (N > 1: one RCCL all-gather of the per-rank accumulation
+        buffers + assemble) -> the frame is complete on the device.  Everything of a frame is stream-ordered (step() is deferred / pipelined
+        inside the library; join() makes the stream wait for it; torch's collective is ordered behind the current = null stream and
+        the null stream behind it), so the only host synchronisation is the one that ends the frame."""
+        done = 0
+        while done < k:
+            n = min(frame_steps, k - done)
+            pt.clearFrameBuffer(None)
+            for _ in range(n):
+                pt.step(None, cam)
+            pt.join(None)
+            if dist is not None:
+                mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16)
+                dist.all_gather_into_tensor(gather_out, gather_in)
+                mv.assemble_tiles(gather_out, world, owned, W, H, frame)
+            mv.synchronize()  # the 64-spp frame is finished: an application would read / resolve it now
+            done += n
+
+    def timed(k):
+        pt.reset_stats()
+        barrier_sync()
+        t0 = time.perf_counter()
+        run_steps(k)
+        barrier_sync()
+        return time.perf_counter() - t0, pt.stats()
+
+    # ---- warmup, then the timed region: EXACTLY K steps (pipelined / batched as the library does by default) ----
+    elapsed, st = None, None
+    if not args.serial_only:
+        run_steps(args.warmup)
+        elapsed, st = timed(args.steps)
+
+    # ---- the non-overlapped pass the roofline comes from: pipeline depth 1, one step per pass, no sibling passes, HIP events around every
+    # kernel on the one stream everything runs on.  Kernel times cannot overlap, so sum(kernel ms) <= wall time of this pass. ----
+    serial = None
+    if (not args.no_serial_pass and world == 1 and not args.emulate_tiles) or args.serial_only:
+        pt.set_pipeline_depth(1)
+        pt.set_batch_steps(1)
+        pt.set_split_small_passes(False)
+        run_steps(args.warmup if args.serial_only else 1)
+        pt.set_profiling(True)
+        k_serial = args.steps if args.serial_only else min(args.steps, 4)
+        s_el, s_st = timed(k_serial)
+        pt.set_profiling(False)
+        serial = (s_el, s_st, k_serial)
+        if args.serial_only:
+            elapsed, st = s_el, s_st
+        else:  # back to the defaults for the CPU-baseline comparison below
+            pt.set_pipeline_depth(3)
+            pt.set_batch_steps(0)
+            pt.set_split_small_passes(True)
 
     rays = float(st["rays"])
     if dist is not None:
@@ -219,34 +258,37 @@ def main():
 
     # ---- roofline of the traversal kernel (DESIGN.md "Algorithmic bytes") ----
     # B_ray = 28 (ray in) + 12 (hit out) + D * (4 + 4 [non-shadow]) + 8 [non-shadow hit]   
-    algo_bytes = st["rays"] * 40 + st["descents"] * 8 + st["shadowDescents"] * 4 + st["hits"] * 8
-    launches = max(int(st["traceLaunches"]), 1)
-    trace_ms = st["traceKernelMs"]
     roofline = None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if args.scene == "dragon" and args.grid_res == 2048 and (W, H) == (1920, 1080) and os.path.exists(tpath):
-        # HBM-side bytes cannot be read live: they come from the separate rocprofv3 --pmc passes of this same command
-        traffic = json.load(open(tpath))
-    if trace_ms > 0:
+    if serial is not None and serial[1]["traceKernelMs"] > 0:
+        s_el, ss, k_serial = serial
+        algo_bytes = ss["rays"] * 40 + ss["descents"] * 8 + ss["shadowDescents"] * 4 + ss["hits"] * 8
+        launches = max(int(ss["traceLaunches"]), 1)
+        trace_ms = ss["traceKernelMs"]
         achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):  # HBM-side bytes cannot be read live: separate rocprofv3 --pmc passes of `bench.py --serial-only` (tools/final_profiles.sh)
+            tj = json.load(open(tpath))
+            if tj.get("scene") == args.scene and tj.get("grid_res") == args.grid_res and (W, H) == (1920, 1080):
+                traffic, traffic_src = int(tj["traffic_bytes_per_ray"] * ss["rays"] / launches), tj["_source"]
         roofline = {
             "bound": "hbm", "kernel": "kPtTraceStream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": int(traffic["traffic_bytes_per_ray"] * st["rays"] / launches) if traffic else None, "traffic_source": traffic["_source"] if traffic else None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "measured_in": "extra non-overlapped pass after the timed region: pipeline depth 1, 1 step per pass, %d steps, HIP events around every kernel on the launch stream"
+                           % k_serial,
             "algorithmic_bytes_per_launch": int(algo_bytes / launches), "avg_launch_ms": round(trace_ms / launches, 4), "launches": launches,
-            "bytes_per_ray": round(algo_bytes / max(st["rays"], 1), 2),
-            "descents_per_ray": round((st["descents"] + st["shadowDescents"]) / max(st["rays"], 1), 2),
-            "trace_share_of_step_time": round(trace_ms / max(st["totalKernelMs"], 1e-9), 3),
-            "trace_kernel_mrays_per_s": round(st["rays"] / (trace_ms * 1e-3) / 1e6, 1),
-            "limiter": "instruction issue (VALU ~80-90 % busy + the CU's shared scalar ALU), not bytes: this octree is cache resident; the HBM-bound configuration is "
-                       "`bench.py --mode stress` (profiles/r01_bench_stress.json: 3.0 TB/s of random 64-byte node lines = 94 % of the chip's measured "
-                       "random-line ceiling, profiles/r01_gfx950_issue_and_gather_costs.txt)",
+            "serial_pass_wall_ms": round(s_el * 1e3, 3), "sum_kernel_ms": round(ss["totalKernelMs"], 3),
+            "bytes_per_ray": round(algo_bytes / max(ss["rays"], 1), 2),
+            "descents_per_ray": round((ss["descents"] + ss["shadowDescents"]) / max(ss["rays"], 1), 2),
+            "trace_share_of_kernel_time": round(trace_ms / max(ss["totalKernelMs"], 1e-9), 3),
+            "shade_share_of_kernel_time": round(ss["shadeKernelMs"] / max(ss["totalKernelMs"], 1e-9), 3),
+            "trace_kernel_mrays_per_s": round(ss["rays"] / (trace_ms * 1e-3) / 1e6, 1),
+            "serial_job_mrays_per_s": round(ss["rays"] / s_el / 1e6, 1),
         }
 
     # ---- CPU baseline (rank 0, single GPU runs only): the oracle on a bounded band of the same frame ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_tiles:
         from oracle import oracle as O  # the checker / baseline -- never part of the measured GPU path
         nodes, attrs, _ = pt.m_intersectorOctreeGPU.download()
         sc = O.Scene(nodes.view(O.NODE_DTYPE), attrs, origin, dps, args.grid_res, info.hasEmission)
@@ -254,7 +296,7 @@ def main():
         Hh = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
         # worker pool sized to this job's CPU share: a 1-GPU box grants 16 cores however many the host shows
         cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), args.cpu_threads)
-        rows = args.cpu_rows or H  # whole frame, one 16-spp iteration: ~10-30 s on 16 cores
+        rows = args.cpu_rows or (H if st["rays"] / max(st["samples"], 1) < 6 else H // 4)  # ~10-30 s of CPU work on 16 cores
         y0 = (H - rows) // 2
         p0, p1 = y0 * W, (y0 + rows) * W
         fb_cpu = np.zeros((W * H, 4), np.float32)
@@ -272,7 +314,8 @@ def main():
         }
 
     if rank == 0:
-        spp = 16 * args.steps
+        spp = 16 * frame_steps
+        names = {"dragon": "xyzrgb_dragon stand-in", "rtcamp": "rtcamp9 stand-in", "cave": "closed cave (rtcamp9-class occlusion)"}
         out = {
             "metric": "Mrays/sec (primary+secondary) at %dx%d, %d spp" % (W, H, spp),
             "value": round(rays / elapsed / 1e6, 2),
@@ -287,12 +330,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s stand-in %d^3 SVO (procedural, seeded), wavefront path trace %dx%d, %d spp = %d steps x 16, 8 bounces + IBL shadow rays" %
-                            ("xyzrgb_dragon" if args.scene == "dragon" else "rtcamp9", args.grid_res, W, H, spp, args.steps),
+                "workload": "%s %d^3 SVO (procedural, pinned by tests/test_scenes.py), wavefront path trace %dx%d, %d steps of 16 spp rendered as %d-spp frames "
+                            "(frame buffer cleared + device synchronised per frame), 8 bounces + IBL shadow rays%s" %
+                            (names[args.scene], args.grid_res, W, H, args.steps, spp, "; SERIAL MODE (pipeline depth 1, batch 1)" if args.serial_only else ""),
                 "voxels": int(info.numberOfVoxels), "dag_nodes": int(info.numberOfNodes), "octree_mb": round(info.numberOfNodes * 64 / 1e6, 1),
                 "triangles": int(len(verts) // 3), "svo_build_s": round(build_s, 3), "setup_s": round(setup_s, 1),
-                "parallelism": "tile-split x%d (256-px blocks round-robin) + 1 RCCL all-gather" % world if world > 1 else "1 GPU",
-                "rays_per_sample": round(rays / max(st["samples"] * (world if world > 1 else 1), 1), 3) if world == 1 else None,
+                "parallelism": ("tile-split x%d (256-px blocks round-robin) + 1 RCCL all-gather per frame" % world) if world > 1 else
+                               ("1 GPU, tile 0 of %d (emulated share)" % args.emulate_tiles if args.emulate_tiles else "1 GPU"),
+                "rays_per_sample": round(rays / max(st["samples"], 1), 3) if world == 1 else None,
                 "device": mv.device_name(),
             },
             "rays": int(rays),

@@ -89,8 +89,9 @@ def densest_band(fb, w, n):
     """start pixel of the n-pixel run of the frame with the most accumulated radiance variation (i.e. through geometry, not sky)"""
     lum = fb[:, :3].sum(1)
     rows = np.abs(np.diff(lum.reshape(-1, w), axis=1)).sum(1)
-    k = n // w
+    k = -(-n // w)  # whole rows that cover n pixels: the band must end inside the frame (the oracle writes every pixel of it)
     best = int(np.argmax(np.convolve(rows, np.ones(k), "valid")))
+    assert best * w + n <= len(fb)
     return best * w
 
 

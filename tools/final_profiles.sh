@@ -2,7 +2,7 @@
 # usage (on the GPU box, repo root): tools/final_profiles.sh <tag>   -- everything the round's profiles/ entries are made from, into gpurun_out/final_<tag>/
 set -o pipefail
 tag=${1:-r01b}; out=gpurun_out/final_$tag; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?run through gpurun}
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench default rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline > $out/stats.log 2>&1; echo "stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
