@@ -138,6 +138,21 @@ MVRT_DI uint32_t selU( lmask m, uint32_t a, uint32_t b ) // lane bit set ? a : b
 }
 #define MVRT_SELKK( m, K1, K0 ) ( { uint32_t r_; asm( "v_cndmask_b32 %0, " #K0 ", " #K1 ", %1" : "=v"( r_ ) : "s"( m ) ); r_; } )	   // bit ? K1 : K0
 #define MVRT_SELK( m, K1, b ) ( { uint32_t r_; asm( "v_cndmask_b32 %0, %1, " #K1 ", %2" : "=v"( r_ ) : "v"( b ), "s"( m ) ); r_; } ) // bit ? K1 : b
+// IEEE minimum of two NaN-free values as ONE v_min_f32 (fminf() makes the compiler quiet possible signalling NaNs first: a v_max x, x per operand)
+MVRT_DI float minF( float a, float b )
+{
+	float r;
+	asm( "v_min_f32 %0, %1, %2" : "=v"( r ) : "v"( a ), "v"( b ) );
+	return r;
+}
+// lane mask of the lanes whose `v` has its sign bit set, one v_cmp at the point of use (as __ballot( (int)v < 0 ) on a value defined under a
+// divergent branch the compiler builds the mask inside the branch and re-materialises it with a v_cndmask + v_cmp pair per use)
+MVRT_DI unsigned long long signMask( uint32_t v )
+{
+	unsigned long long m;
+	asm( "v_cmp_gt_i32 %0, 0, %1" : "=s"( m ) : "v"( v ) );
+	return m;
+}
 typedef float v2f __attribute__( ( ext_vector_type( 2 ) ) );
 typedef uint32_t u4v __attribute__( ( ext_vector_type( 4 ) ) );
 typedef __attribute__( ( address_space( 3 ) ) ) u4v LdsU4; // (u4v: clang vector, assignable across address spaces)
@@ -293,15 +308,35 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 	uint32_t chunkNext = 0, chunkEnd = 0;
 	bool exhausted = false;
 
-	// per-lane state.  st: 0 idle, 1 traversing, 2 finished and holding a result that is not stored yet
+	// per-lane state.  st: 0 idle, 1 traversing, finished and holding a result that is not stored yet: 2 = miss, 3 = hit (the lane's slab state is
+	// untouched since the step that found the leaf: t and nMajor are re-derived from it at flush time instead of being selected into two more
+	// registers in EVERY step), 4 = irregular ray (result parked in tx1 / level)
 	uint32_t st = 0;
 	bool isShadow = false;
 	uint32_t ray = 0;
 	float dtx = 0, dty = 0, dtz = 0, tx1 = 0, ty1 = 0, tz1 = 0;
 	uint32_t vMask = 0, vMaskHi = 24u, node = 0, nodeMask = 0, level = 0, childMask = 8u, pending = 0, inLds = 0, descents = 0;
 	uint64_t path = 0;
-	float resT = MVRT_MAXF;
-	int resN = -1;
+	// result of a finished lane (st >= 2), from its parked state
+	auto finishedHit = [&]( StreamHit* h ) {
+		h->t = MVRT_MAXF;
+		h->nMajor = -1;
+		if( st == 3u ) // :324-334 -- the same arithmetic as the step that accepted the leaf
+		{
+			const float scale = mvrt_u2f( ( 127u - level ) << 23 );
+			const float tx0 = tx1 - dtx * scale, ty0 = ty1 - dty * scale, tz0 = tz1 - dtz * scale;
+			const float S = fmaxf( fmaxf( tx0, ty0 ), tz0 );
+			h->t = S;
+			h->nMajor = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
+		}
+		else if( st == 4u )
+		{
+			h->t = tx1;
+			h->nMajor = (int)level;
+		}
+		h->path = h->t != MVRT_MAXF ? path : 0ull;
+		h->descents = descents;
+	};
 
 	for( ;; )
 	{
@@ -309,13 +344,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		const unsigned long long idleMask = __ballot( st != 1u );
 		const uint32_t nIdle = __popcll( idleMask );
 		{
-			if( st == 2u ) // flush results of the lanes that finished since the last refill
+			if( st >= 2u ) // flush results of the lanes that finished since the last refill
 			{
 				StreamHit h;
-				h.t = resT;
-				h.nMajor = resN;
-				h.path = resT != MVRT_MAXF ? path : 0ull;
-				h.descents = descents;
+				finishedHit( &h );
 				io.store( ray, h, isShadow );
 				st = 0;
 			}
@@ -331,7 +363,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						unsigned long long base = 0;
 						const uint32_t c = chunk;
 						if( lane == 0 ) base = atomicAdd( cursor, (unsigned long long)c );
-						base = __shfl( base, 0, 64 );
+						// readfirstlane, not a shuffle: the cursor state (and with it `exhausted` and the exit test of the step loop) is then
+						// wave-uniform FOR THE COMPILER -- scalar registers, scalar branches, and the lane masks of the step loop stay in SGPRs
+						// across its exit instead of being copied to VGPRs in every iteration
+						base = (unsigned long long)__builtin_amdgcn_readfirstlane( (uint32_t)base ) | ( (unsigned long long)__builtin_amdgcn_readfirstlane( (uint32_t)( base >> 32 ) ) << 32 );
 						if( base >= total )
 						{
 							exhausted = true;
@@ -377,8 +412,6 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						tz1 = ( s.hiz - ro.z ) * iz;
 						descents = 0;
 						path = 0;
-						resT = MVRT_MAXF;
-						resN = -1;
 						vMaskHi = vMask | 24u;
 						if( min3f( tx1, ty1, tz1 ) < max3f( t0x, t0y, t0z ) ) // :275-278 misses the root box
 						{
@@ -388,8 +421,12 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 								 ( ( mvrt_f2u( tz1 - t0z ) & 0x7F800000u ) == 0x7F800000u ) )
 						{
 							// irregular ray (inf / NaN slab delta): exact reference emulation, see traceIrregular
+							float resT = MVRT_MAXF;
+							int resN = -1;
 							traceIrregular<EMBED>( s, tx1, ty1, tz1, t0x, t0y, t0z, vMask, mySpill, spillStride, &resT, &resN, &path, &descents );
-							st = 2u;
+							tx1 = resT; // parked where finishedHit() looks for an st == 4 result
+							level = (uint32_t)resN;
+							st = 4u;
 						}
 						else
 						{
@@ -413,13 +450,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			if( __ballot( st == 1u ) == 0ull )
 			{
 				if( !exhausted ) continue; // every ray just loaded missed the root box: go round again
-				if( st == 2u )			   // final flush
+				if( st >= 2u )			   // final flush
 				{
 					StreamHit h;
-					h.t = resT;
-					h.nMajor = resN;
-					h.path = resT != MVRT_MAXF ? path : 0ull;
-					h.descents = descents;
+					finishedHit( &h );
 					io.store( ray, h, isShadow );
 				}
 				break; // every lane idle and the stream is empty: the wave retires
@@ -558,11 +592,9 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					tz1 = mvrt_u2f( e.w & 0x7FFFFFFFu );
 				}
 			}
-			if( hit ) // :324-334
+			if( hit ) // :324-334 (t and nMajor: finishedHit)
 			{
-				resT = S;
-				resN = ( S == tx0 ) ? 1 : ( ( S == ty0 ) ? 2 : 0 );
-				st = 2u;
+				st = 3u;
 			}
 		}
 		const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
@@ -581,9 +613,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		// mask of every lane lives bit-sliced in three SGPR pairs (+ a "first visit" mask) while the loop runs.
 		lmask cmX = __ballot( ( childMask & 1u ) != 0u ), cmY = __ballot( ( childMask & 2u ) != 0u ), cmZ = __ballot( ( childMask & 4u ) != 0u );
 		lmask mFirst = __ballot( ( childMask & 8u ) != 0u );
+		lmask actM = __ballot( st == 1u ), hitM = 0ull, missM = 0ull;
 		for( ;; )
 		{
-			const lmask act = __ballot( st == 1u );
+			const lmask act = actM;
 #ifdef MVRT_UTIL_STATS
 			if( lane == 0 ) // per wave-ITERATION tallies (the block above counts refill events)
 			{
@@ -608,10 +641,11 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			// first exit event = lexicographic minimum of (t1, axis); flips = mid-plane events of unset axes that come before it, i.e.
 			// before EVERY exit event (an axis' own exit never precedes its mid-plane: tM <= t1).  (tM_a, a) < (t1_b, b) is "tM_a <= t1_b" for
 			// a < b and "tM_a < t1_b" for a > b
-			const float T = fminf( fminf( tx1, ty1 ), tz1 );
-			const lmask fX = ~X & __ballot( txM <= fminf( ty1, tz1 ) );
+			const float mXY = minF( tx1, ty1 ), mYZ = minF( ty1, tz1 );
+			const float T = minF( mXY, tz1 );
+			const lmask fX = ~X & __ballot( txM <= mYZ );
 			const lmask fY = ~Y & __ballot( tyM < tx1 ) & __ballot( tyM <= tz1 );
-			const lmask fZ = ~Z & __ballot( tzM < fminf( tx1, ty1 ) );
+			const lmask fZ = ~Z & __ballot( tzM < mXY );
 			// order of the flips among themselves: (tM, axis) lexicographic
 			const lmask xy = __ballot( txM <= tyM ), xz = __ballot( txM <= tzM ), yz = __ballot( tyM <= tzM );
 			const lmask n1 = fX | fY | fZ, n2 = ( fX & fY ) | ( fZ & ( fX | fY ) ), n3 = fX & fY & fZ; // a 2nd / 3rd / 4th candidate exists geometrically
@@ -729,25 +763,22 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			}
 			// hit (:324-334) or miss: the lane holds its result until the next refill.  Selects, not a branch: some lane finishes in
 			// almost every iteration of a 64-lane wave anyway
-			{
-				// (these two masks come straight from a v_cmp: on gfx940+ a VALU-written SGPR needs two wait states before a VALU
-				// reads it, and the compiler cannot see a reader inside asm -- hence the s_nop in the template)
-				uint32_t nm;
-				asm( "s_nop 1\n\tv_cndmask_b32 %0, 0, 2, %1" : "=v"( nm ) : "s"( __ballot( S == ty0 ) ) );
-				asm( "s_nop 1\n\tv_cndmask_b32 %0, %0, 1, %1" : "+v"( nm ) : "s"( __ballot( S == tx0 ) ) );
-				resT = mvrt_u2f( selU( mHit, mvrt_f2u( S ), mvrt_f2u( resT ) ) );
-				resN = (int)selU( mHit, nm, (uint32_t)resN );
-				st = MVRT_SELK( mHit | ( mPop & ~mPopOk ), 2, st );
-			}
+			// (a hit only changes the lane's state: t and nMajor are re-derived by finishedHit() from the slab state the lane keeps)
 			// bit-sliced child mask of the lanes that popped = the sign bits of the restored exit times; a descent starts a first visit
 			// (`popped` is zero for the lanes that did not pop)
-			cmX = ( cmX & ~mPopOk ) | __ballot( (int)popped.y < 0 );
-			cmY = ( cmY & ~mPopOk ) | __ballot( (int)popped.z < 0 );
-			cmZ = ( cmZ & ~mPopOk ) | __ballot( (int)popped.w < 0 );
+			cmX = ( cmX & ~mPopOk ) | signMask( popped.y );
+			cmY = ( cmY & ~mPopOk ) | signMask( popped.z );
+			cmZ = ( cmZ & ~mPopOk ) | signMask( popped.w );
 			mFirst = ( mFirst & ~mPopOk ) | mGo;
-			const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
-			if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
+			// which lanes are still traversing / hold a hit / hold a miss is kept in lane masks (scalar unit) while the loop runs
+			const lmask mMiss = mPop & ~mPopOk;
+			hitM |= mHit;
+			missM |= mMiss;
+			actM &= ~( mHit | mMiss );
+			const int nAct = __builtin_popcount( (uint32_t)actM ) + __builtin_popcount( (uint32_t)( actM >> 32 ) ); // (two 32-bit counts: a 64-bit one is compared on the VALU)
+			if( nAct == 0 || ( nAct <= 64 - MVRT_REFILL_MIN && !exhausted ) ) break;
 		}
+		st = LANE( hitM ) ? 3u : ( LANE( missM ) ? 2u : st );
 		childMask = LANE( mFirst ) ? 8u : ( ( LANE( cmX ) ? 1u : 0u ) | ( LANE( cmY ) ? 2u : 0u ) | ( LANE( cmZ ) ? 4u : 0u ) );
 #endif
 	}
