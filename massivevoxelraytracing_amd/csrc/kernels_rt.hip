@@ -646,7 +646,8 @@ struct PtIO
 	}
 };
 template <bool EMBED>
-__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk )
+__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk,
+																			uint32_t raysPerLane, uint32_t minWaves )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
 	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
@@ -657,23 +658,18 @@ __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtPara
 	io.shadowKind = shadowKind;
 	io.dNormal = io.dShadow = io.nHits = 0;
 	const uint64_t total = (uint64_t)io.n * nKinds;
-#ifdef MVRT_RAYS_PER_LANE
-	{
-		// small launches: fewer, longer-lived waves keep their lanes refilled instead of idling in a long tail
-		uint64_t wantWaves = total / ( 64ull * MVRT_RAYS_PER_LANE ) + 1;
-		if( wantWaves < MVRT_MIN_WAVES ) wantWaves = MVRT_MIN_WAVES;
-		if( blockIdx.x >= wantWaves ) return;
-	}
-#endif
-	// chunk was sized for the upper bound; shrink it when few paths are alive so every wave gets work
+	// The grid is sized on the host for the upper bound (live counts stay on the device).  A launch with few rays is not throughput- but
+	// latency-bound -- its time is the longest ray's iterations times the time of one iteration, and an iteration takes as long as the
+	// SIMD's co-resident waves make it -- so it keeps only as many waves as give each lane raysPerLane rays (at least minWaves): fewer waves
+	// per SIMD, each with its lanes refilled from a longer stretch of the stream.  The other workgroups retire at once.
 	uint64_t nWaves = gridDim.x;
-#ifdef MVRT_RAYS_PER_LANE
+	if( raysPerLane )
 	{
-		uint64_t wantWaves = total / ( 64ull * MVRT_RAYS_PER_LANE ) + 1;
-		if( wantWaves < MVRT_MIN_WAVES ) wantWaves = MVRT_MIN_WAVES;
+		uint64_t wantWaves = total / ( 64ull * raysPerLane ) + 1;
+		if( wantWaves < minWaves ) wantWaves = minWaves;
+		if( blockIdx.x >= wantWaves ) return;
 		if( wantWaves < nWaves ) nWaves = wantWaves;
 	}
-#endif
 	uint64_t c = total / ( nWaves * 4 );
 	c = ( c + 63 ) / 64 * 64;
 	if( c < 64 ) c = 64;
@@ -1016,6 +1012,7 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		if( ws.spill )
 		{
 			int g = streamGrid( nSamples * nKinds, nCUs );
+			uint32_t smallRpl = 0, smallMinW = 0;
 			{
 				// a pass that shares the GPU with a sibling pass on another stream takes only 1/div of the wave slots, so that the two
 				// really run side by side (a full persistent grid would hold every slot until its own tail)
@@ -1026,13 +1023,17 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 				const int div = stage > divMaxStage ? 1 : ( envDiv > 0 ? envDiv : frame.traceGridDiv );
 				if( div > 1 && g > nCUs * STREAM_WAVES_PER_CU / div ) g = nCUs * STREAM_WAVES_PER_CU / div;
 				// experiment knob: waves per CU of a full-grid traversal launch (32 = every slot the register budget allows and then some)
+				static const uint32_t envRpl = getenv( "MVRT_SMALL_RPL" ) ? (uint32_t)atoi( getenv( "MVRT_SMALL_RPL" ) ) : 0u;
+				static const uint32_t envMinW = getenv( "MVRT_SMALL_MINW" ) ? (uint32_t)atoi( getenv( "MVRT_SMALL_MINW" ) ) : 1024u;
+				smallRpl = envRpl;
+				smallMinW = envMinW;
 				static const int wpc = getenv( "MVRT_TRACE_WAVES_PER_CU" ) ? atoi( getenv( "MVRT_TRACE_WAVES_PER_CU" ) ) : 0;
 				if( wpc > 0 && g > nCUs * wpc / ( div > 1 ? div : 1 ) ) g = nCUs * wpc / ( div > 1 ? div : 1 );
 			}
 			if( svo.embedded )
-				hipLaunchKernelGGL( kPtTraceStream<true>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
+				hipLaunchKernelGGL( kPtTraceStream<true>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
 			else
-				hipLaunchKernelGGL( kPtTraceStream<false>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ) );
+				hipLaunchKernelGGL( kPtTraceStream<false>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
 		}
 		else
 		{
