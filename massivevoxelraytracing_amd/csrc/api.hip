@@ -137,6 +137,8 @@ struct mvrt_svo
 	uint32_t* psumCold = nullptr; // non-embedded flavour only
 	uint2* attrs = nullptr;
 	uint64_t* morton = nullptr; // only after build()
+	DevBuf topTable;			// per-prefix start of the nVoxelsPSum walk (SvoDev::topTable), embedded flavour
+	uint32_t topLevels = 0;
 	mutable DevBuf wsBuf;		// traversal workspace (spill rows + cursor), sized on demand
 	mutable DevBuf pathBuf;
 	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
@@ -160,6 +162,8 @@ struct mvrt_svo
 		psumCold = nullptr;
 		attrs = nullptr;
 		morton = nullptr;
+		topTable.release();
+		topLevels = 0;
 		float es = info.emissionScale;
 		memset( &info, 0, sizeof( info ) );
 		info.emissionScale = es;
@@ -203,6 +207,8 @@ struct mvrt_svo
 		d.levels = info.levels;
 		d.rootIndex = info.numberOfNodes - 1; // root = last node, :250
 		d.rootMask = rootMask;
+		d.topTable = topTable.as<uint2>();
+		d.topLevels = topLevels;
 		return d;
 	}
 };
@@ -213,6 +219,22 @@ static int ptFlush( mvrt_pt* pt );
 static int ptDrain( mvrt_pt* pt );
 static int ownerFlush( const mvrt_svo* s ) { return s && s->owner ? ptFlush( s->owner ) : 0; }
 static int ownerDrain( const mvrt_svo* s ) { return s && s->owner ? ptDrain( s->owner ) : 0; }
+
+// after nodes are in place: the prefix table that shortens every nVoxelsPSum walk (voxelIndexFromPath).  6 levels = 2 MiB: stays in L2.
+static int buildTopTable( mvrt_svo* s, hipStream_t st )
+{
+	s->topTable.release();
+	s->topLevels = 0;
+	if( !s->info.embeddedMask || !s->nodes || s->info.levels == 0 ) return 0;
+	static const int envK = getenv( "MVRT_TOP_LEVELS" ) ? atoi( getenv( "MVRT_TOP_LEVELS" ) ) : 6;
+	uint32_t k = (uint32_t)( envK < 0 ? 0 : ( envK > 8 ? 8 : envK ) );
+	if( k > s->info.levels ) k = s->info.levels;
+	if( k == 0 ) return 0;
+	if( s->topTable.alloc( ( 1ull << ( 3 * k ) ) * sizeof( uint2 ) ) ) return 1;
+	if( launchBuildTopTable( s->nodes, s->info.numberOfNodes - 1, k, s->topTable.as<uint2>(), st ) ) return 1;
+	s->topLevels = k;
+	return 0;
+}
 
 static int ilog2Exact( int v )
 {
@@ -273,6 +295,7 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	svo->info.totalDumpedVoxels = 0;
 	setBounds( svo, origin, dps, gridRes );
 	svo->rootMask = ( (const uint8_t*)nodes68Host )[(uint64_t)( numberOfNodes - 1 ) * 68];
+	if( buildTopTable( svo, st ) ) return 1;
 	MVRT_HIP( hipStreamSynchronize( st ) );
 	return 0;
 }
@@ -291,6 +314,8 @@ static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origi
 	svo->info.totalDumpedVoxels = r.totalDumped;
 	setBounds( svo, origin, dps, gridRes );
 	MVRT_HIP( hipMemcpy( &svo->rootMask, svo->masks + ( r.nNodes - 1 ), 1, hipMemcpyDeviceToHost ) );
+	if( buildTopTable( svo, nullptr ) ) return 1;
+	MVRT_HIP( hipDeviceSynchronize() );
 	return 0;
 }
 MVRT_EXPORT int mvrt_svo_build_ex( mvrt_svo* svo, const float* verticesHost, const float* vcolorsHost, const float* vemissionsHost, uint64_t nVertices, void* stream,
@@ -448,7 +473,7 @@ MVRT_EXPORT int mvrt_compact_indices( const uint8_t* keepDev, uint64_t n, uint32
 		return 0;
 	}
 	DevBuf scratch;
-	if( scratch.alloc( ( n / 256 + 2 ) * 4 ) ) return 1;
+	if( scratch.alloc( ( n / 256 + 8 ) * 4 ) ) return 1; // (+ padding: the scan reads whole 16-byte quads)
 	if( launchCompactIndices( keepDev, n, dstIndexDev, keptDev, scratch.as<uint32_t>(), (hipStream_t)stream ) ) return 1;
 	MVRT_HIP( hipStreamSynchronize( (hipStream_t)stream ) ); // scratch is freed on return
 	return 0;
@@ -817,7 +842,7 @@ MVRT_EXPORT uint64_t mvrt_pt_owned_pixels( const mvrt_pt* pt ) { return pt ? pt-
 static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
 	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP * pt->effectiveBatch();
-	const uint64_t nBlocks = cap / 256 + 2;
+	const uint64_t nBlocks = cap / 256 + 8; // (+ padding: the scan reads whole 16-byte quads)
 	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays + 2 x 8-byte path arrays,
 	// 4 bytes per word; 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
 	const uint64_t words = cap * ( 32 + 6 + 3 + 3 + 4 );

@@ -383,41 +383,56 @@ MVRT_DI uint32_t blockRank( bool keep, uint32_t* waveCnt /* LDS, 4 entries */ )
 }
 
 // exclusive scan of blockCount[0..nBlocks) in place by ONE workgroup of 1024 threads; total -> *totalOut.
-// nBlocks is read from device memory when nDev != null (n = *nDev items).
+// nBlocks is read from device memory when nDev != null (n = *nDev items).  Tiles of 4096 counts: every thread owns four consecutive counts
+// (one 16-byte load and store, coalesced), scans them, the workgroup scans the 1024 thread sums (wave shuffles + 16 wave totals in LDS) and a
+// running total carries over to the next tile.  The count arrays are padded to a multiple of 4 entries (allocWorkSlot, mvrt_compact_indices).
 __global__ void __launch_bounds__( 1024 ) kScanBlockCounts( uint32_t* __restrict__ blockCount, uint64_t nItemsHost, const uint32_t* __restrict__ nItemsDev,
 															 uint32_t* __restrict__ totalOut, unsigned long long* __restrict__ rayStats = nullptr, int nKinds = 0, int shadowKind = 0 )
 {
-	__shared__ uint32_t part[1024];
+	__shared__ uint32_t waveTot[16];
+	__shared__ uint32_t carryLds;
 	uint64_t nItems = nItemsDev ? (uint64_t)*nItemsDev : nItemsHost;
 	if( rayStats && threadIdx.x == 0 ) // ray accounting of the stage that was just traced (intersect() calls)
 	{
 		atomicAdd( &rayStats[0], (unsigned long long)nItems * nKinds );
 		if( shadowKind ) atomicAdd( &rayStats[1], (unsigned long long)nItems );
 	}
-	uint32_t nBlocks = (uint32_t)( ( nItems + CBLOCK - 1 ) / CBLOCK );
-	uint32_t per = ( nBlocks + 1023 ) / 1024;
-	uint32_t beg = threadIdx.x * per;
-	uint32_t end = beg + per < nBlocks ? beg + per : nBlocks;
-	uint32_t sum = 0;
-	for( uint32_t i = beg; i < end; i++ ) sum += blockCount[i];
-	part[threadIdx.x] = sum;
-	__syncthreads();
-	for( uint32_t off = 1; off < 1024; off <<= 1 ) // Hillis-Steele inclusive over the 1024 partials
+	const uint32_t nBlocks = (uint32_t)( ( nItems + CBLOCK - 1 ) / CBLOCK );
+	const uint32_t lane = threadIdx.x & ( WAVE - 1 ), wave = threadIdx.x / WAVE;
+	uint32_t carry = 0;
+	for( uint32_t base = 0; base < nBlocks; base += 4096 )
 	{
-		uint32_t v = part[threadIdx.x];
-		if( threadIdx.x >= off ) v += part[threadIdx.x - off];
+		const uint32_t i0 = base + threadIdx.x * 4;
+		uint4 c = make_uint4( 0u, 0u, 0u, 0u );
+		if( i0 < nBlocks ) c = *(const uint4*)( blockCount + i0 ); // entries past nBlocks inside the last quad are padding: masked below
+		if( i0 + 1 >= nBlocks ) c.y = 0u;
+		if( i0 + 2 >= nBlocks ) c.z = 0u;
+		if( i0 + 3 >= nBlocks ) c.w = 0u;
+		const uint32_t mine = c.x + c.y + c.z + c.w;
+		uint32_t incl = mine; // inclusive scan of the thread sums inside the wave
+		for( int o = 1; o < WAVE; o <<= 1 )
+		{
+			const uint32_t v = __shfl_up( incl, o, WAVE );
+			if( (int)lane >= o ) incl += v;
+		}
+		if( lane == WAVE - 1 ) waveTot[wave] = incl;
 		__syncthreads();
-		part[threadIdx.x] = v;
+		uint32_t before = carry;
+		for( uint32_t w = 0; w < wave; w++ ) before += waveTot[w];
+		if( threadIdx.x == 1023 ) carryLds = before + incl;
+		const uint32_t e0 = before + incl - mine;
+		if( i0 + 3 < nBlocks ) *(uint4*)( blockCount + i0 ) = make_uint4( e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z );
+		else if( i0 < nBlocks ) // the last, partial quad: nothing is written past nBlocks
+		{
+			blockCount[i0] = e0;
+			if( i0 + 1 < nBlocks ) blockCount[i0 + 1] = e0 + c.x;
+			if( i0 + 2 < nBlocks ) blockCount[i0 + 2] = e0 + c.x + c.y;
+		}
+		__syncthreads();
+		carry = carryLds;
 		__syncthreads();
 	}
-	uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-	for( uint32_t i = beg; i < end; i++ )
-	{
-		uint32_t c = blockCount[i];
-		blockCount[i] = run;
-		run += c;
-	}
-	if( threadIdx.x == 1023 && totalOut ) *totalOut = part[1023];
+	if( threadIdx.x == 0 && totalOut ) *totalOut = carry;
 }
 
 __global__ void __launch_bounds__( CBLOCK ) kCountFlags( const uint8_t* __restrict__ keep, uint64_t n, uint32_t* __restrict__ blockCount )

@@ -60,6 +60,31 @@ int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, ui
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
+// topTable (SvoDev): one thread per path prefix of `k` levels walks it from the root exactly as voxelIndexFromPath would
+__global__ void __launch_bounds__( 256 ) kBuildTopTable( const Node64* __restrict__ nodes, uint32_t rootIndex, uint32_t k, uint2* __restrict__ table )
+{
+	const uint32_t nPrefix = 1u << ( 3u * k );
+	for( uint32_t p = blockIdx.x * 256 + threadIdx.x; p < nPrefix; p += gridDim.x * 256 )
+	{
+		uint32_t n = rootIndex, v = 0;
+		bool alive = true;
+		for( uint32_t l = 0; l < k && alive; l++ )
+		{
+			const uint32_t c = ( p >> ( 3u * ( k - 1u - l ) ) ) & 7u;
+			const uint32_t child = nodes[n].children[c];
+			v += nodes[n].psum[c];
+			if( child == MVRT_LEAF ) alive = l + 1 == k; // a voxel (only legal at the last level of the octree) or an absent child
+			n = child & 0xFFFFFFu;
+		}
+		table[p] = alive ? make_uint2( n, v ) : make_uint2( 0u, 0u );
+	}
+}
+int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream )
+{
+	hipLaunchKernelGGL( kBuildTopTable, dim3( cappedGrid( 1ull << ( 3 * k ) ) ), dim3( 256 ), 0, stream, nodes, rootIndex, k, table );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
 __global__ void __launch_bounds__( 256 ) kNodesTo68( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ psumCold, uint32_t nNodes,
 													  uint8_t* __restrict__ nodes68, int nonEmbedded )
 {

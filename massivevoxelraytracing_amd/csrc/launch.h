@@ -89,6 +89,7 @@ int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStr
 int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, uint32_t* psumCold, int nonEmbedded, hipStream_t stream );
 int launchNodesTo68( const Node64* nodes, const uint8_t* masks, const uint32_t* psumCold, uint32_t nNodes, uint8_t* nodes68, int nonEmbedded, hipStream_t stream );
 int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, uint64_t nNodes, hipStream_t stream ); // in place, after a build
+int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream ); // embedded flavour only
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 
 // GPU SVO construction (svo_build.hip)

@@ -170,6 +170,11 @@ struct SvoDev
 	uint32_t levels;
 	uint32_t rootIndex; // nNodes - 1
 	uint32_t rootMask;
+	// embedded flavour: what the first topLevels levels of the nVoxelsPSum walk add up to, per path prefix: topTable[prefix] = { node reached
+	// (index), sum of nVoxelsPSum along the prefix }.  The top of a DAG is a tree (sharing starts near the leaves), the table is per PATH, so it
+	// is exact either way; entries of prefixes that leave the octree are never looked up (only paths of real hits are resolved).
+	const uint2* topTable;
+	uint32_t topLevels; // 0 = no table
 };
 
 MVRT_DI f3 getHitN( int major, f3 rd ) // voxCommon.hpp:564-577

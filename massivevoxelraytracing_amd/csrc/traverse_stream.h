@@ -65,8 +65,15 @@ struct StreamHit
 // CONSUMER of a hit (dense kernels, every lane busy), not inside the divergent traversal loop.
 MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 {
-	uint32_t n = s.rootIndex, v = 0;
-	for( uint32_t l = 0; l < s.levels; l++ )
+	uint32_t n = s.rootIndex, v = 0, l0 = 0;
+	if( s.topLevels ) // one table lookup replaces the first topLevels dependent gathers
+	{
+		const uint2 e = s.topTable[(uint32_t)( path >> ( 3u * ( s.levels - s.topLevels ) ) )];
+		n = e.x;
+		v = e.y;
+		l0 = s.topLevels;
+	}
+	for( uint32_t l = l0; l < s.levels; l++ )
 	{
 		const uint32_t c = (uint32_t)( path >> ( 3u * ( s.levels - 1u - l ) ) ) & 7u;
 		const Node64* nd = s.nodes + n;
