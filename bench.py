@@ -248,7 +248,18 @@ def main():
             pt.set_split_small_passes(True)
 
     rays = float(st["rays"])
+    gather_ok = None
     if dist is not None:
+        # outside the timed region: every rank looks its own pixels up in the assembled frame of the last gather (bit for bit)
+        from massivevoxelraytracing_amd import tiles
+        mv.synchronize()
+        full = frame.cpu().numpy().reshape(-1, 4)
+        mine = pt.read_framebuffer()
+        g = tiles.global_pixel_index(W, H, rank, world)
+        ok = g >= 0
+        flag = torch.tensor([1.0 if np.array_equal(full[g[ok]], mine[ok]) else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_ok = bool(flag[0] > 0)
         t = torch.tensor([elapsed, rays], dtype=torch.float64, device="cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -335,9 +346,10 @@ def main():
                             (names[args.scene], args.grid_res, W, H, args.steps, spp, "; SERIAL MODE (pipeline depth 1, batch 1)" if args.serial_only else ""),
                 "voxels": int(info.numberOfVoxels), "dag_nodes": int(info.numberOfNodes), "octree_mb": round(info.numberOfNodes * 64 / 1e6, 1),
                 "triangles": int(len(verts) // 3), "svo_build_s": round(build_s, 3), "setup_s": round(setup_s, 1),
-                "parallelism": ("tile-split x%d (256-px blocks round-robin) + 1 RCCL all-gather per frame" % world) if world > 1 else
+                "parallelism": ("tile-split x%d (256-px blocks round-robin) + 1 RCCL all-gather per frame" % world) if dist is not None else
                                ("1 GPU, tile 0 of %d (emulated share)" % args.emulate_tiles if args.emulate_tiles else "1 GPU"),
                 "rays_per_sample": round(rays / max(st["samples"], 1), 3) if world == 1 else None,
+                "gather_ok": gather_ok,
                 "device": mv.device_name(),
             },
             "rays": int(rays),

@@ -71,19 +71,29 @@ def build(force=False, verbose=True):
     return OUT
 
 
+APPS = {
+    # name: (source, extra compile/link flags)
+    "rtcamp_batch": ("rtcamp_batch.cpp", []),
+    # single-process N-GPU tile driver: HIP runtime types for RCCL's stream argument + librccl
+    "tile_render": ("tile_render.cpp", ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]),
+}
+
+
 def build_apps(verbose=True):
-    """g++ the C++ host applications that sit on the header-only mirrors (apps/) against libmvrt_hip.so."""
+    """g++ the C++ host applications that sit on the header-only mirrors (apps/) against libmvrt_hip.so.  Returns the path of rtcamp_batch."""
     root = os.path.dirname(HERE)
-    out = os.path.join(root, "apps", "rtcamp_batch")
-    src = os.path.join(root, "apps", "rtcamp_batch.cpp")
-    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(root, "apps", "scene_io.hpp"))):
-        return out
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "apps"), src, "-o", out,
-           "-L", HERE, "-l:libmvrt_hip.so", "-Wl,-rpath," + HERE, "-Wl,--allow-shlib-undefined"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return out
+    deps = [os.path.join(root, "apps", "scene_io.hpp")] + [os.path.join(root, "include", "mvrt", f) for f in ("PathTracer.hpp", "IntersectorOctreeGPU.hpp")] + [os.path.join(root, "include", "mvrt.h")]
+    for name, (src_name, extra) in APPS.items():
+        out = os.path.join(root, "apps", name)
+        src = os.path.join(root, "apps", src_name)
+        if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(f) for f in [src] + deps):
+            continue
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unused-result", "-pthread", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "apps"), src, "-o", out,
+               "-L", HERE, "-l:libmvrt_hip.so", "-Wl,-rpath," + HERE, "-Wl,--allow-shlib-undefined"] + extra
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return os.path.join(root, "apps", "rtcamp_batch")
 
 
 if __name__ == "__main__":

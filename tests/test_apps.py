@@ -125,3 +125,65 @@ def test_batch_driver_frames_match_the_oracle(tmp_path):
         assert got.max() > 0
     assert len(grids) >= 2  # the resolution ramp really changed the grid between frames
     assert not os.path.exists(tmp_path / "003.ppm") and not os.path.exists(tmp_path / "007.ppm")  # frame-range sharding
+
+
+@pytest.mark.gpu
+def test_tile_render_single_process_rccl_matches_the_oracle(tmp_path):
+    """apps/tile_render: the native multi-GPU host path (one process, one PathTracer + one RCCL communicator per device, tile split,
+    ncclAllGather of the accumulation buffers, assemble, resolve).  Run on the GPUs this box has (1): the collective and the assembly
+    really execute, and the gathered frame equals the ORACLE's frame bit for bit -- float accumulation buffer and resolved bytes."""
+    from massivevoxelraytracing_amd import build as b
+    from oracle import oracle as O
+    b.build_apps(verbose=False)
+    exe = os.path.join(ROOT, "apps", "tile_render")
+    tris = bunny_tris()
+    obj = tmp_path / "bunny.obj"
+    write_obj(obj, tris)
+    hdr = os.path.join(GOLDEN, "monks_forest_s.hdr")
+    W, H, steps, res = 200, 113, 2, 128
+    out = subprocess.check_output([exe, str(obj), hdr, str(tmp_path / "f.ppm"), "--gpus", "8", "--size", str(W), str(H), "--res", str(res), "--steps", str(steps),
+                                   "--dump-f32", str(tmp_path / "f.f32"), "--dump-camera", str(tmp_path / "cam.txt")]).decode()
+    assert "devices" in out and "best frame" in out
+    lines = open(tmp_path / "cam.txt").read().split("\n")
+    view = np.array([float.fromhex(t) for t in lines[0].split()], np.float32)
+    proj = np.array([float.fromhex(t) for t in lines[1].split()], np.float32)
+    t = lines[2].split()
+    focus, lens_r, ox, oy, oz, dps = (float.fromhex(x) for x in t[:6])
+    assert int(t[6]) == res
+    v = tris.reshape(-1, 3)
+    emis = np.zeros_like(v)
+    lo = v.min(0)
+    ext = np.float32((v.max(0) - lo).max())
+    emis[v[:, 1] > lo[1] + np.float32(0.94) * ext] = np.array([1.0, 0.85, 0.6], np.float32)
+    sc = O.build_scene_from_triangles(tris, res, np.ones_like(v).reshape(-1, 9), emis.reshape(-1, 9), origin=np.array([ox, oy, oz], np.float32), dps=np.float32(dps))
+    rgba, hw, hh = O.decode_rgbe(open(hdr, "rb").read())
+    Hd = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    cam = O.camera_from_matrices(view, proj, focus, lens_r)
+    fb = np.zeros((W * H, 4), np.float32)
+    for it in range(steps):
+        fb, _, _ = sc.render_pt(Hd, cam, W, H, it, math_mode=1, fb=fb, threads=8)
+    got = np.fromfile(tmp_path / "f.f32", np.float32).reshape(W * H, 4)
+    assert np.array_equal(got, fb)
+    ppm = open(tmp_path / "f.ppm", "rb").read()
+    hdr_len = len(b"P6\n%d %d\n255\n" % (W, H))
+    assert np.array_equal(np.frombuffer(ppm[hdr_len:], np.uint8).reshape(H * W, 3), O.resolve(fb, math_mode=1)[:, :3])
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_runs_on_one_gpu():
+    """bench.py's N > 1 code path (torch.distributed over RCCL: d2d copy of the accumulation buffer, all_gather_into_tensor, assemble on
+    the device, all ordered on one stream) executed with a world of ONE rank (MVRT_FORCE_DIST=1), in a fresh process; the line reports
+    that every rank found its own pixels, bit for bit, in the assembled frame."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MVRT_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360", "--grid-res", "512",
+                                   "--detail", "0.25", "--no-cpu-baseline", "--no-serial-pass"], env=env, timeout=600).decode()
+    line = json.loads(out.strip().split("\n")[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["gather_ok"] is True
+    assert "RCCL" in line["config"]["parallelism"]
