@@ -69,20 +69,23 @@ def stress(args, mv):
     desc = de.to_host().astype(np.uint64)
     hits = int((t.to_host() != mv.MAX_FLOAT).sum())
     algo = n_rays * 40 + int(desc.sum()) * 8 + hits * 8
-    line_bytes = int(desc.sum()) * 64  # what a dependent pointer chase really moves: one 64-byte node line per descent
+    # what the dependent pointer chase really moves: one NEW 64-byte line per two descents (two-level bricks; the in-between descent re-reads the
+    # line the previous one fetched)
+    line_bytes = int(desc.sum()) * 32
     gbs = algo * args.steps / el / 1e9
     print(json.dumps({
         "metric": "Mrays/sec (incoherent rays, HBM-resident synthetic octree)", "value": round(n_rays * args.steps / el / 1e6, 2), "unit": "Mrays/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic %d^3 non-DAG SVO, %d random voxels, %d incoherent rays per step (trace + vIndex resolve)" % (res, n_vox, n_rays),
-                   "voxels": int(info.numberOfVoxels), "nodes": int(info.numberOfNodes), "node_gb": round(info.numberOfNodes * 64 / 1e9, 2),
+                   "voxels": int(info.numberOfVoxels), "nodes": int(info.numberOfNodes), "reference_node_gb": round(info.numberOfNodes * 68 / 1e9, 2),
+                   "resident_structure_gb": round(svo.traversal_bytes() / 1e9, 2),
                    "embedded_mask": int(info.embeddedMask), "svo_build_s": round(build_s, 2), "hits": hits, "descents_per_ray": round(float(desc.mean()), 2)},
-        "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<false>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<2> (tree flavour: two-level bricks)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
                      "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "random_line_ceiling_gbs": RANDOM_LINE_CEILING_GBS,
                      "line_frac_of_ceiling": round(line_bytes * args.steps / el / 1e9 / RANDOM_LINE_CEILING_GBS, 3),
-                     "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts the 64-byte node line each descent pulls from HBM; "
+                     "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts one new 64-byte brick line per two descents; "
                              "random_line_ceiling_gbs = what the chip serves for divergent 64-byte-line gathers at 128 GiB footprint "
                              "(tools/calib/gather_rate.hip, profiles/r01_gfx950_issue_and_gather_costs.txt)"},
     }), flush=True)
@@ -104,7 +107,7 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra non-overlapped pass the roofline numbers come from")
     ap.add_argument("--serial-only", action="store_true", help="run ONLY the non-overlapped pass (pipeline depth 1, batch 1): the command profiles/ *_serial_kernel_stats.csv is taken from")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--voxels", type=float, default=6.5e8, help="stress mode: random voxels of the synthetic octree")
+    ap.add_argument("--voxels", type=float, default=1.05e9, help="stress mode: random voxels of the synthetic octree")
     ap.add_argument("--rays", type=float, default=1.6e7, help="stress mode: incoherent rays per step")
     ap.add_argument("--mode", default="pt", choices=["pt", "primary", "stress"], help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2)")
     ap.add_argument("--emulate-tiles", type=int, default=0, help="diagnostic: render only tile 0 of N on one GPU (predicts per-rank time of an N-GPU run)")

@@ -103,6 +103,11 @@ int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_t numberOfNo
 					 float dps, int gridRes, int hasEmission, int embeddedMask, void* stream );
 int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info );
 int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale ); /* m_emissionScale (:273) */
+/* bytes of the device structure the traversal and mvrt_svo_download work from (the reference's layout would be numberOfNodes * 68):
+ * 64-byte lines per node (+ a 16 MiB prefix table) for DAG octrees; for GPU-built octrees WITHOUT node sharing whose masks are not embedded
+ * ("tree" flavour: MVRT_BUILD_NO_DAG with >= 0xFFFFFF nodes or MVRT_BUILD_NO_EMBEDDED_MASK) 5 bytes per node + one 64-byte two-level brick
+ * per node of every second level. */
+uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo );
 /* m_nodeBuffer / m_vAttributeBuffer (:265-266): the device arrays.  Attributes are the reference's VoxelAttirb[numberOfVoxels]; nodes are
  * this library's 64-byte lines {u32 children[8]; u32 nVoxelsPSum[8]} (the reference's 68-byte node minus its leading mask word, which rides
  * in bits 24-31 of the parent's pointer) -- use mvrt_svo_download for the reference layout. */

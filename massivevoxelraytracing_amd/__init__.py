@@ -58,6 +58,7 @@ SIGNATURES = {
     "mvrt_svo_upload": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp, _f32, _i32, _i32, _i32, _vp]),
     "mvrt_svo_get_info": (_i32, [_vp, _vp]),
     "mvrt_svo_set_emission_scale": (_i32, [_vp, _f32]),
+    "mvrt_svo_traversal_bytes": (_u64, [_vp]),
     "mvrt_svo_node_buffer_dev": (_vp, [_vp]),
     "mvrt_svo_attribute_buffer_dev": (_vp, [_vp]),
     "mvrt_pt_download_pmj": (_i32, [_vp, _vp]),
@@ -276,6 +277,9 @@ class IntersectorOctreeGPU:
     m_hasEmission = property(lambda s: s.info().hasEmission)
     m_nodeBuffer = property(lambda s: lib().mvrt_svo_node_buffer_dev(s._h))  # device pointers (:265-266)
     m_vAttributeBuffer = property(lambda s: lib().mvrt_svo_attribute_buffer_dev(s._h))
+
+    def traversal_bytes(self):
+        return lib().mvrt_svo_traversal_bytes(self._h)
 
     def hasEmission(self):
         return bool(self.info().hasEmission)

@@ -135,6 +135,11 @@ struct mvrt_svo
 	Node64* nodes = nullptr;
 	uint8_t* masks = nullptr;
 	uint32_t* psumCold = nullptr; // non-embedded flavour only
+	// tree flavour (GPU-built octrees without node sharing whose masks are not embedded): `nodes` = two-level bricks, `masks` = per-node mask,
+	// treeFirst = per-node first child (reference numbering), node ranges per builder level
+	uint32_t* treeFirst = nullptr;
+	uint32_t tree = 0, treeRoot = 0, nBricks = 0;
+	uint32_t treeLevelBase[24] = { 0 }, treeLevelCount[24] = { 0 };
 	uint2* attrs = nullptr;
 	uint64_t* morton = nullptr; // only after build()
 	DevBuf topTable;			// per-prefix start of the nVoxelsPSum walk (SvoDev::topTable), embedded flavour
@@ -155,6 +160,9 @@ struct mvrt_svo
 		if( nodes ) (void)hipFree( nodes );
 		if( masks ) (void)hipFree( masks );
 		if( psumCold ) (void)hipFree( psumCold );
+		if( treeFirst ) (void)hipFree( treeFirst );
+		treeFirst = nullptr;
+		tree = treeRoot = nBricks = 0;
 		if( attrs ) (void)hipFree( attrs );
 		if( morton ) (void)hipFree( morton );
 		nodes = nullptr;
@@ -209,6 +217,8 @@ struct mvrt_svo
 		d.rootMask = rootMask;
 		d.topTable = topTable.as<uint2>();
 		d.topLevels = topLevels;
+		d.tree = tree;
+		d.treeRoot = treeRoot;
 		return d;
 	}
 };
@@ -305,6 +315,12 @@ static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origi
 	svo->nodes = r.nodes;
 	svo->masks = r.masks;
 	svo->psumCold = r.psumCold;
+	svo->tree = r.tree;
+	svo->treeRoot = r.treeRoot;
+	svo->nBricks = r.nBricks;
+	svo->treeFirst = r.treeFirst;
+	memcpy( svo->treeLevelBase, r.treeLevelBase, sizeof( svo->treeLevelBase ) );
+	memcpy( svo->treeLevelCount, r.treeLevelCount, sizeof( svo->treeLevelCount ) );
 	svo->attrs = r.attrs;
 	svo->morton = r.morton;
 	svo->info.numberOfNodes = r.nNodes;
@@ -354,6 +370,13 @@ MVRT_EXPORT int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info )
 	*info = svo->info;
 	return 0;
 }
+MVRT_EXPORT uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo )
+{
+	if( !svo || !svo->nodes ) return 0;
+	const uint64_t n = svo->info.numberOfNodes;
+	if( svo->tree ) return (uint64_t)svo->nBricks * sizeof( Node64 ) + n * 5;
+	return n * sizeof( Node64 ) + n + ( svo->psumCold ? n * 32 : 0 ) + svo->topTable.bytes;
+}
 MVRT_EXPORT const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->nodes : nullptr; }
 MVRT_EXPORT const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->attrs : nullptr; }
 MVRT_EXPORT int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale )
@@ -371,7 +394,13 @@ MVRT_EXPORT int mvrt_svo_download( const mvrt_svo* svo, void* nodes68Host, void*
 	{
 		DevBuf raw;
 		if( raw.alloc( (uint64_t)svo->info.numberOfNodes * 68 ) ) return 1;
-		if( launchNodesTo68( svo->nodes, svo->masks, svo->psumCold, svo->info.numberOfNodes, raw.as<uint8_t>(), svo->info.embeddedMask ? 0 : 1, st ) ) return 1;
+		if( svo->tree )
+		{
+			if( launchTreeTo68( svo->masks, svo->treeFirst, svo->treeLevelBase, svo->treeLevelCount, (int)svo->info.levels, svo->info.numberOfNodes, svo->info.numberOfVoxels,
+								raw.as<uint8_t>(), st ) )
+				return 1;
+		}
+		else if( launchNodesTo68( svo->nodes, svo->masks, svo->psumCold, svo->info.numberOfNodes, raw.as<uint8_t>(), svo->info.embeddedMask ? 0 : 1, st ) ) return 1;
 		MVRT_HIP( hipMemcpyAsync( nodes68Host, raw.p, raw.bytes, hipMemcpyDeviceToHost, st ) );
 		MVRT_HIP( hipStreamSynchronize( st ) );
 	}

@@ -73,12 +73,12 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 #ifndef MVRT_TRACE_WAVES
 #define MVRT_TRACE_WAVES 7 // waves per SIMD the traversal kernels are register-budgeted for (72 VGPRs)
 #endif
-template <bool EMBED>
+template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
-	traceStream<EMBED>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask, ws.spillMask );
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING * 64];
+	traceStream<FL>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask, ws.spillMask );
 }
 
 struct PrimaryIO
@@ -122,12 +122,12 @@ struct PrimaryIO
 		if( descentsOut ) descentsOut[pixelIdx] = r.descents;
 	}
 };
-template <bool EMBED>
+template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
-	traceStream<EMBED>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING * 64];
+	traceStream<FL>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
 						ws.spillMask );
 }
 
@@ -244,8 +244,9 @@ int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, c
 		BatchIO io = { rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, paths, descents };
 		int grid = streamGrid( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
-		if( svo.embedded ) hipLaunchKernelGGL( kTraceBatchStream<true>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
-		else hipLaunchKernelGGL( kTraceBatchStream<false>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		if( svo.embedded ) hipLaunchKernelGGL( kTraceBatchStream<0>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		else if( svo.tree ) hipLaunchKernelGGL( kTraceBatchStream<2>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
+		else hipLaunchKernelGGL( kTraceBatchStream<1>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
 		if( vIndex )
 			hipLaunchKernelGGL( kResolveVIndex, dim3( persistentGrid( n, 256, numCUs(), 8 ) ), dim3( 256 ), 0, stream, svo, n, t, paths, isShadow, vIndex, (uchar4*)nullptr );
 		MVRT_HIP( hipGetLastError() );
@@ -330,8 +331,9 @@ int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const Came
 		io.rdKeep = mk3( 0, 0, 0 );
 		int grid = streamGrid( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
-		if( svo.embedded ) hipLaunchKernelGGL( kRenderPrimaryStream<true>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
-		else hipLaunchKernelGGL( kRenderPrimaryStream<false>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		if( svo.embedded ) hipLaunchKernelGGL( kRenderPrimaryStream<0>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		else if( svo.tree ) hipLaunchKernelGGL( kRenderPrimaryStream<2>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
+		else hipLaunchKernelGGL( kRenderPrimaryStream<1>, dim3( grid ), dim3( 64 ), 0, stream, io, ws, streamChunk( n, grid ) );
 		if( needPaths )
 			hipLaunchKernelGGL( kResolveVIndex, dim3( persistentGrid( n, 256, numCUs(), 8 ) ), dim3( 256 ), 0, stream, svo, n, t, ws.paths, (const uint8_t*)nullptr, vIndex,
 								showVertexColor ? rgba : (uchar4*)nullptr );
@@ -660,12 +662,12 @@ struct PtIO
 		nHits += ( kind != 1 && isHit ) ? 1u : 0u;
 	}
 };
-template <bool EMBED>
+template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk,
 																			uint32_t raysPerLane, uint32_t minWaves )
 {
 	__shared__ uint4 ring[MVRT_RING * 64];
-	__shared__ uint32_t ringMask[EMBED ? 1 : MVRT_RING * 64];
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING * 64];
 	PtIO io;
 	io.table = P.buf.selfDev;
 	io.setIdx = setIdx;
@@ -689,7 +691,7 @@ __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtPara
 	c = ( c + 63 ) / 64 * 64;
 	if( c < 64 ) c = 64;
 	if( c > chunk ) c = chunk;
-	traceStream<EMBED>( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
+	traceStream<FL>( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
 						ws.spillMask );
 	unsigned long long dN = waveSum( (unsigned long long)io.dNormal ), dS = waveSum( (unsigned long long)io.dShadow ), nH = waveSum( (unsigned long long)io.nHits );
 #ifdef MVRT_UTIL_STATS
@@ -1046,9 +1048,11 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 				if( wpc > 0 && g > nCUs * wpc / ( div > 1 ? div : 1 ) ) g = nCUs * wpc / ( div > 1 ? div : 1 );
 			}
 			if( svo.embedded )
-				hipLaunchKernelGGL( kPtTraceStream<true>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
+				hipLaunchKernelGGL( kPtTraceStream<0>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
+			else if( svo.tree )
+				hipLaunchKernelGGL( kPtTraceStream<2>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
 			else
-				hipLaunchKernelGGL( kPtTraceStream<false>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
+				hipLaunchKernelGGL( kPtTraceStream<1>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
 		}
 		else
 		{

@@ -60,6 +60,66 @@ int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, ui
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
+// ---- tree flavour -> reference layout (mvrt_svo_download).  Builder level 0 = parents of voxels, levels - 1 = root; nodes of a level are in
+// morton order, their children consecutive in the level below, the voxels consecutive in morton order: a node covers a contiguous voxel range.
+struct TreeLevels
+{
+	uint32_t base[24], count[24];
+	int levels;
+};
+MVRT_DI uint32_t treeFirstVoxel( const uint32_t* __restrict__ first, uint32_t idx, int l ) // first voxel below node idx of builder level l
+{
+	for( ; l > 0; l-- ) idx = first[idx];
+	return first[idx];
+}
+__global__ void __launch_bounds__( 256 ) kTreeTo68( const uint8_t* __restrict__ masks, const uint32_t* __restrict__ first, TreeLevels L, uint32_t nNodes, uint32_t nVoxels,
+													 uint8_t* __restrict__ nodes68 )
+{
+	for( uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < nNodes; idx += (uint64_t)gridDim.x * 256 )
+	{
+		int l = 0;
+		while( l + 1 < L.levels && idx >= L.base[l + 1] ) l++;
+		const uint32_t mask = masks[idx];
+		uint32_t* dst = (uint32_t*)( nodes68 + idx * 68 );
+		dst[0] = mask;
+		uint32_t k = first[idx], run = 0; // child nodes (l > 0) or voxels (l == 0), consecutive from k
+		const uint32_t myVox = l > 0 ? treeFirstVoxel( first, k, l - 1 ) : k;
+		for( int c = 0; c < 8; c++ )
+		{
+			uint32_t child = MVRT_LEAF, cnt = 0;
+			if( mask >> c & 1u )
+			{
+				if( l == 0 ) cnt = 1;
+				else
+				{
+					child = k;
+					const uint32_t endLevel = L.base[l - 1] + L.count[l - 1];
+					const uint32_t nextVox = k + 1 < endLevel ? treeFirstVoxel( first, k + 1, l - 1 ) : nVoxels;
+					cnt = nextVox - ( myVox + run );
+				}
+				k++;
+			}
+			dst[1 + c] = child;
+			dst[9 + c] = run; // nVoxelsPSum: voxels below the children before c (exclusive prefix, also for absent children)
+			run += cnt;
+		}
+	}
+}
+int launchTreeTo68( const uint8_t* masks, const uint32_t* first, const uint32_t* levelBase, const uint32_t* levelCount, int levels, uint32_t nNodes, uint32_t nVoxels, uint8_t* nodes68,
+					hipStream_t stream )
+{
+	TreeLevels L;
+	for( int l = 0; l < 24; l++ )
+	{
+		L.base[l] = levelBase[l];
+		L.count[l] = levelCount[l];
+	}
+	L.levels = levels;
+	hipLaunchKernelGGL( kTreeTo68, dim3( cappedGrid( nNodes ) ), dim3( 256 ), 0, stream, masks, first, L, nNodes, nVoxels, nodes68 );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+
 // topTable (SvoDev): one thread per path prefix of `k` levels walks it from the root exactly as voxelIndexFromPath would
 __global__ void __launch_bounds__( 256 ) kBuildTopTable( const Node64* __restrict__ nodes, uint32_t rootIndex, uint32_t k, uint2* __restrict__ table )
 {

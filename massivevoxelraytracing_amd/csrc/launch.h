@@ -89,6 +89,9 @@ int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStr
 int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, uint32_t* psumCold, int nonEmbedded, hipStream_t stream );
 int launchNodesTo68( const Node64* nodes, const uint8_t* masks, const uint32_t* psumCold, uint32_t nNodes, uint8_t* nodes68, int nonEmbedded, hipStream_t stream );
 int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, uint64_t nNodes, hipStream_t stream ); // in place, after a build
+// tree flavour -> the reference's 68-byte nodes (mask, children[8], nVoxelsPSum[8]) from { mask, first child } per node
+int launchTreeTo68( const uint8_t* masks, const uint32_t* first, const uint32_t* levelBase, const uint32_t* levelCount, int levels, uint32_t nNodes, uint32_t nVoxels, uint8_t* nodes68,
+					hipStream_t stream );
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream ); // embedded flavour only
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 
@@ -102,6 +105,11 @@ struct SvoBuildResult
 	uint64_t* morton; // kept for parity checks (sorted unique codes)
 	uint32_t nNodes, nVoxels, hasEmission, embedded;
 	uint64_t totalDumped;
+	// "tree" flavour (no DAG, masks not embedded): `nodes` holds nBricks two-level bricks, `masks` the per-node masks and `treeFirst` the
+	// per-node first-child index (reference numbering); node ranges per builder level (0 = parents of voxels)
+	uint32_t tree, nBricks, treeRoot;
+	uint32_t* treeFirst;
+	uint32_t treeLevelBase[24], treeLevelCount[24];
 };
 // flags: 1 = no DAG de-duplication (every sibling group is a node), 2 = never embed masks in child pointers
 int svoBuildFromTriangles( const float* vertsHost, const float* colsHost, const float* emisHost, uint64_t nVertices, f3 origin, float dps, int gridRes, int flags,

@@ -175,6 +175,9 @@ struct SvoDev
 	// is exact either way; entries of prefixes that leave the octree are never looked up (only paths of real hits are resolved).
 	const uint2* topTable;
 	uint32_t topLevels; // 0 = no table
+	// tree flavour (svo_build.hip): `nodes` are two-level bricks, treeRoot is where the traversal starts (a brick index, or a voxel index for a
+	// one-level octree); hits report the voxel index directly
+	uint32_t tree, treeRoot;
 };
 
 MVRT_DI f3 getHitN( int major, f3 rd ) // voxCommon.hpp:564-577

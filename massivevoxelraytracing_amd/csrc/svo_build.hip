@@ -660,6 +660,74 @@ __global__ void __launch_bounds__( BB ) kMakeNodesDirect( const Task* __restrict
 		}
 	}
 }
+// ---- "tree" flavour (no DAG and too many nodes for embedded masks, or embedding switched off): the nodes are never materialised as 64-byte
+// lines.  In a tree built level by level in morton order the children of a node are CONSECUTIVE nodes of the level below, so a node is
+// { mask, index of its first child } (5 bytes; for the parents of voxels: index of their first voxel), and what the traversal reads are
+// BRICKS: one 64-byte line per node of every second level holding, for each of its 8 children, the child's mask and where the child's own
+// children start -- a line fetch advances the traversal TWO levels (traverse_stream.h, flavour 2). -------------------------------------------
+__global__ void __launch_bounds__( BB ) kMakeNodesTree( const Task* __restrict__ tasks, uint64_t n, const uint32_t* __restrict__ blockOff, uint32_t nodeBase, int bottomLevel,
+														 uint8_t* __restrict__ cMask, uint32_t* __restrict__ cFirst, Task* __restrict__ tasksOut )
+{
+	__shared__ uint32_t wc[BB / WAVE];
+	const uint64_t nBlocks = ( n + BB - 1 ) / BB;
+	for( uint64_t vb = blockIdx.x; vb < nBlocks; vb += gridDim.x )
+	{
+		uint64_t i = vb * BB + threadIdx.x;
+		bool head = i < n ? ( i == 0 || ( tasks[i - 1].morton >> 3 ) != ( tasks[i].morton >> 3 ) ) : false;
+		uint32_t r = rankInBlock( head, wc );
+		if( head )
+		{
+			uint32_t mask = 0, run = 0;
+			const uint64_t parent = tasks[i].morton >> 3;
+			for( uint64_t j = i; j < n && ( tasks[j].morton >> 3 ) == parent; j++ )
+			{
+				mask |= 1u << (uint32_t)( tasks[j].morton & 7 );
+				run += tasks[j].count;
+			}
+			const uint32_t g = blockOff[vb] + r;
+			const uint64_t idx = (uint64_t)nodeBase + g;
+			cMask[idx] = (uint8_t)mask;
+			cFirst[idx] = bottomLevel ? (uint32_t)i : tasks[i].child; // first voxel (= its vIndex) / first child node: the rest follow consecutively
+			Task o;
+			o.morton = parent;
+			o.child = (uint32_t)idx;
+			o.count = run;
+			tasksOut[g] = o;
+		}
+	}
+}
+// bricks of one (odd) builder level: node r = levelBase + g has children k = cFirst[r] + j in the level below.  grandBase / grandBrickBase
+// translate the children's first-child indices (nodes two levels below) into brick indices; childIsBottom: the children are parents of voxels
+// and their cFirst already IS a voxel index.
+__global__ void __launch_bounds__( BB ) kMakeBricks( const uint8_t* __restrict__ cMask, const uint32_t* __restrict__ cFirst, uint32_t levelBase, uint32_t count, int childIsBottom,
+													  uint32_t grandBase, uint32_t grandBrickBase, Node64* __restrict__ bricksOfLevel )
+{
+	for( uint64_t g = (uint64_t)blockIdx.x * BB + threadIdx.x; g < count; g += (uint64_t)gridDim.x * BB )
+	{
+		const uint32_t r = levelBase + (uint32_t)g;
+		const uint32_t mask = cMask[r];
+		uint32_t k = cFirst[r];
+		Node64 nd;
+		uint32_t lo = 0, hi = 0;
+		for( int c = 0; c < 8; c++ )
+		{
+			nd.children[c] = MVRT_LEAF;
+			nd.psum[c] = 0;
+			if( mask >> c & 1u )
+			{
+				const uint32_t m = cMask[k];
+				nd.children[c] = childIsBottom ? cFirst[k] : grandBrickBase + ( cFirst[k] - grandBase );
+				if( c < 4 ) lo |= m << ( 8 * c );
+				else hi |= m << ( 8 * ( c - 4 ) );
+				k++;
+			}
+		}
+		nd.psum[0] = lo;
+		nd.psum[1] = hi;
+		nd.psum[2] = mask; // the brick root's own mask: what a descent INTO this brick fetches
+		bricksOfLevel[g] = nd;
+	}
+}
 // distinct parents per level for ALL levels in one pass (the reference's octreeTaskInit counters, voxKernel.cu:257-265)
 __global__ void __launch_bounds__( BB ) kLevelCounts( const uint64_t* __restrict__ morton, uint64_t n, int levels, unsigned long long* __restrict__ counts )
 {
@@ -836,6 +904,9 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 	std::vector<Node64*> levelNodes; // per-level node arrays, concatenated at the end
 	std::vector<uint8_t*> levelMasks;
 	std::vector<uint32_t> levelCount;
+	bool tree = false; // no DAG + no embedded masks: compact { mask, first child } nodes + two-level bricks instead of 64-byte lines per node
+	Buf treeFirst, bricks;
+	uint32_t treeLevelBase[24] = { 0 }, treeLevelCount[24] = { 0 }, treeBrickBase[24] = { 0 }, nBricks = 0;
 	auto freeLevels = [&]() {
 		for( Node64* p : levelNodes ) (void)hipFree( p );
 		for( uint8_t* p : levelMasks ) (void)hipFree( p );
@@ -873,15 +944,44 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 					mvrtSetError( "mvrt_svo_build: %llu nodes exceed 32-bit node indices", total );
 					return 1;
 				}
-				Node64* nn = nullptr;
+				tree = total >= 0xFFFFFFull || ( flags & 2 );
 				uint8_t* mm = nullptr;
-				MVRT_HIP( hipMalloc( (void**)&nn, total * sizeof( Node64 ) ) );
 				MVRT_HIP( hipMalloc( (void**)&mm, total ) );
-				levelNodes.push_back( nn );
 				levelMasks.push_back( mm );
 				levelCount.push_back( (uint32_t)total );
+				if( tree )
+				{
+					// node ranges per builder level (0 = parents of voxels ... levels - 1 = root) and brick ranges of the odd levels
+					unsigned long long nb = 0, nBr = 0;
+					for( int l = 0; l < levels; l++ )
+					{
+						treeLevelBase[l] = (uint32_t)nb;
+						treeLevelCount[l] = (uint32_t)hc[l];
+						treeBrickBase[l] = (uint32_t)nBr;
+						nb += hc[l];
+						if( l & 1 ) nBr += hc[l];
+					}
+					nBricks = (uint32_t)nBr;
+					if( treeFirst.alloc( total * 4 ) || bricks.alloc( ( nBr ? nBr : 1 ) * sizeof( Node64 ) ) ) return 1;
+					levelNodes.push_back( nullptr );
+				}
+				else
+				{
+					Node64* nn = nullptr;
+					MVRT_HIP( hipMalloc( (void**)&nn, total * sizeof( Node64 ) ) );
+					levelNodes.push_back( nn );
+				}
 			}
-			hipLaunchKernelGGL( kMakeNodesDirect, dim3( gridFor( nInput ) ), dim3( BB ), 0, st, cur, (uint64_t)nInput, blockCnt.as<uint32_t>(), nodeBase, levelNodes[0], levelMasks[0], nxt );
+			if( tree )
+			{
+				hipLaunchKernelGGL( kMakeNodesTree, dim3( gridFor( nInput ) ), dim3( BB ), 0, st, cur, (uint64_t)nInput, blockCnt.as<uint32_t>(), nodeBase, level == 0 ? 1 : 0, levelMasks[0],
+									treeFirst.as<uint32_t>(), nxt );
+				if( level & 1 )
+					hipLaunchKernelGGL( kMakeBricks, dim3( gridFor( nGroups ) ), dim3( BB ), 0, st, levelMasks[0], treeFirst.as<uint32_t>(), treeLevelBase[level], nGroups, level - 1 == 0 ? 1 : 0,
+										level >= 2 ? treeLevelBase[level - 2] : 0u, level >= 2 ? treeBrickBase[level - 2] : 0u, bricks.as<Node64>() + treeBrickBase[level] );
+			}
+			else
+				hipLaunchKernelGGL( kMakeNodesDirect, dim3( gridFor( nInput ) ), dim3( BB ), 0, st, cur, (uint64_t)nInput, blockCnt.as<uint32_t>(), nodeBase, levelNodes[0], levelMasks[0], nxt );
 			MVRT_HIP( hipStreamSynchronize( st ) );
 			nodeBase += nGroups;
 			nInput = nGroups;
@@ -978,6 +1078,37 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 		}
 		MVRT_HIP( hipStreamSynchronize( st ) );
 		freeLevels();
+	}
+	if( tree ) // nothing left to convert: the traversal reads the bricks, download rebuilds the reference's nodes from { mask, first child }
+	{
+		uint32_t he = 0;
+		MVRT_HIP( hipMemcpyAsync( &he, hasEmission, 4, hipMemcpyDeviceToHost, st ) );
+		MVRT_HIP( hipStreamSynchronize( st ) );
+		MVRT_HIP( hipGetLastError() );
+		out->nodes = (Node64*)bricks.detach();
+		out->masks = (uint8_t*)masks.detach();
+		out->psumCold = nullptr;
+		out->treeFirst = (uint32_t*)treeFirst.detach();
+		out->tree = 1;
+		out->nBricks = nBricks;
+		for( int l = 0; l < 24; l++ )
+		{
+			out->treeLevelBase[l] = treeLevelBase[l];
+			out->treeLevelCount[l] = treeLevelCount[l];
+		}
+		// where the traversal starts: the root is the single node of builder level levels - 1.  Odd level: it is a brick root -> its brick.
+		// Even level: it is an "in-brick child" whose children (level levels - 2) are brick roots -> the first of them (or, for a one-level
+		// octree, voxel 0)
+		const int rl = levels - 1;
+		out->treeRoot = ( rl & 1 ) ? treeBrickBase[rl] : ( rl == 0 ? 0u : treeBrickBase[rl - 1] );
+		out->attrs = (uint2*)attrs.detach();
+		out->morton = (uint64_t*)morton.detach();
+		out->nNodes = nNodes;
+		out->nVoxels = nVoxels;
+		out->hasEmission = he;
+		out->embedded = 0;
+		out->totalDumped = totalDumped;
+		return 0;
 	}
 	const bool embed = nNodes < 0xFFFFFFu && !( flags & 2 );
 	if( embed )

@@ -1,9 +1,16 @@
 // traverse_stream.h -- persistent-wave octree traversal for gfx950.
 //
-// Two node-reference flavours (template parameter EMBED):
-//   EMBED = true  : child pointers carry the child's occupancy mask in bits 24-31 (ENABLE_EMBEDED_MASK,
+// Three node-reference flavours (template parameter FL; EMBED = FL == 0, TREE = FL == 2):
+//   FL = 2 (tree) : octrees WITHOUT node sharing whose masks cannot be embedded (the HBM-resident 8192^3 stress octree).  The children of a
+//                   node are consecutive nodes, so a child reference is (first child, mask) and the traversal reads two-level BRICKS: the
+//                   64-byte line of a node on every second level holds, per child, the child's mask and where the child's children start.
+//                   A lane sitting on a brick root keeps (brick index, own mask); descending fetches (child mask, first grandchild) from the
+//                   line it already touched, and only the next descent -- onto the grandchild's brick, index = first + popcount(mask below) --
+//                   is a new line.  One dependent HBM fetch per TWO levels; the hit voxel's index falls out of the last step
+//                   (first voxel + popcount), so no nVoxelsPSum walk and no voxel path either.  svo_build.hip (kMakeBricks) builds them.
+//   FL = 0 (EMBED): child pointers carry the child's occupancy mask in bits 24-31 (ENABLE_EMBEDED_MASK,
 //                   voxCommon.hpp:7-9); < 2^24 nodes; node offsets fit 32 bits.
-//   EMBED = false : plain 32-bit child indices (up to 2^32-2 nodes, e.g. the 8192^3 non-DAG stress octree).  The
+//   FL = 1        : plain 32-bit child indices (up to 2^32-2 nodes, e.g. the 8192^3 non-DAG stress octree).  The
 //                   reference reads a node's mask from the node when it is entered (voxCommon.hpp:353-356), i.e. two
 //                   dependent misses per descent on an HBM-resident tree.  Here the 8 child masks sit in the parent's
 //                   64-byte line next to the 8 child pointers (nVoxelsPSum moves to a cold array that only
@@ -65,6 +72,7 @@ struct StreamHit
 // CONSUMER of a hit (dense kernels, every lane busy), not inside the divergent traversal loop.
 MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 {
+	if( s.tree ) return (uint32_t)path; // tree flavour: the traversal already reports the voxel's index (first voxel of its parent + rank)
 	uint32_t n = s.rootIndex, v = 0, l0 = 0;
 	if( s.topLevels ) // one table lookup replaces the first topLevels dependent gathers
 	{
@@ -99,6 +107,7 @@ struct TraceCore
 	float lox, loy, loz, hix, hiy, hiz;
 	uint32_t rootRef; // rootIndex | rootMask << 24 (voxCommon.hpp:306)
 	uint32_t rootIndex, rootMask;
+	uint32_t levelsM1; // tree flavour: levels - 1 = depth of the parents of voxels (they are "in-brick" nodes, like every second level above them)
 };
 MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
 {
@@ -107,8 +116,9 @@ MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
 	c.lox = s.lower.x; c.loy = s.lower.y; c.loz = s.lower.z;
 	c.hix = s.upper.x; c.hiy = s.upper.y; c.hiz = s.upper.z;
 	c.rootRef = s.rootIndex | ( s.rootMask << 24 );
-	c.rootIndex = s.rootIndex;
+	c.rootIndex = s.tree ? s.treeRoot : s.rootIndex;
 	c.rootMask = s.rootMask;
+	c.levelsM1 = s.levels - 1u;
 	return c;
 }
 
@@ -179,10 +189,37 @@ MVRT_DI uint32_t bfi( uint32_t mask, uint32_t a, uint32_t b ) // (a & mask) | (b
 // all finite never enter the fast loop (whose v_max3/v_min3 assume NaN-free data); they are traced here, one
 // lane at a time if need be, with the reference's exact operation order and a stack in the HBM spill rows
 // (two 16-byte rows per slot).  They are measure-zero in rendering; cost is irrelevant.
-template <bool EMBED>
+// one descent of the tree flavour (see the header): from an in-brick node (node = where its children start, nodeMask = its mask) onto the
+// child's brick -- or onto a voxel, whose index is recorded -- and from a brick root (node = brick index) to one of its children
+MVRT_DI void treeDescend( const Node64* __restrict__ bricks, uint32_t levelsM1, uint32_t level, uint32_t childIndex, uint32_t* node, uint32_t* nodeMask, uint64_t* leafV )
+{
+	if( ( ( levelsM1 - level ) & 1u ) == 0u ) // in-brick node
+	{
+		const uint32_t at = *node + (uint32_t)__popc( *nodeMask & ( ( 1u << childIndex ) - 1u ) );
+		if( level == levelsM1 ) // its children are voxels
+		{
+			*leafV = at;
+			*node = MVRT_LEAF;
+		}
+		else
+		{
+			*node = at;
+			*nodeMask = bricks[at].psum[2]; // the brick root's own mask: THE dependent line fetch of these two levels
+		}
+	}
+	else
+	{
+		const Node64* nd = bricks + *node; // the line fetched when this brick was entered
+		*nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu;
+		*node = nd->children[childIndex];
+	}
+}
+
+template <int FL>
 MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1, float t0x, float t0y, float t0z, uint32_t vMask, uint4* __restrict__ mySpill,
 							 uint64_t spillStride, float* resT, int* resN, uint64_t* pathOut, uint32_t* descentsOut )
 {
+	constexpr bool EMBED = FL == 0, TREE = FL == 2;
 	const float dtx = tx1 - t0x, dty = ty1 - t0y, dtz = tz1 - t0z;
 	uint32_t node = EMBED ? s.rootRef : s.rootIndex, nodeMask = s.rootMask, level = 0, childMask = 8u, sp = 0, descents = 0;
 	uint64_t path = 0;
@@ -240,6 +277,10 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 				{
 					node = s.nodes[node & 0xFFFFFFu].children[childIndex];
 				}
+				else if( TREE )
+				{
+					treeDescend( s.nodes, s.levelsM1, level, childIndex, &node, &nodeMask, &path );
+				}
 				else
 				{
 					const Node64* nd = s.nodes + node;
@@ -247,7 +288,7 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 					node = nd->children[childIndex];
 				}
 				descents++;
-				path = ( path << 3 ) | childIndex;
+				if( !TREE ) path = ( path << 3 ) | childIndex;
 				tx1 = x1;
 				ty1 = y1;
 				tz1 = z1;
@@ -291,11 +332,12 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 // (one store site, many lanes per store instruction), then load new rays into them; (2) one traversal step for
 // every active lane: straight-line bit arithmetic (v_bfi / v_bfe selects instead of compare-select chains)
 // followed by three shallow branches: descend (with push), pop, hit.
-template <bool EMBED, class IO>
+template <int FL, class IO>
 MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING][64] */,
 						  uint4* __restrict__ spill /* [levels][spillStride] */, uint64_t spillStride, uint64_t spillLane, uint32_t* __restrict__ ldsMask = nullptr /* [MVRT_RING][64], !EMBED */,
 						  uint32_t* __restrict__ spillMask = nullptr /* [levels][spillStride], !EMBED */ )
 {
+	constexpr bool EMBED = FL == 0, TREE = FL == 2;
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = (uint32_t)total64;
 	const Node64* __restrict__ nodes = s.nodes;
@@ -430,7 +472,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 							// irregular ray (inf / NaN slab delta): exact reference emulation, see traceIrregular
 							float resT = MVRT_MAXF;
 							int resN = -1;
-							traceIrregular<EMBED>( s, tx1, ty1, tz1, t0x, t0y, t0z, vMask, mySpill, spillStride, &resT, &resN, &path, &descents );
+							traceIrregular<FL>( s, tx1, ty1, tz1, t0x, t0y, t0z, vMask, mySpill, spillStride, &resT, &resN, &path, &descents );
 							tx1 = resT; // parked where finishedHit() looks for an st == 4 result
 							level = (uint32_t)resN;
 							st = 4u;
@@ -552,6 +594,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
 					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
 				}
+				else if( TREE )
+				{
+					treeDescend( nodes, s.levelsM1, level, childIndex, &node, &nodeMask, &path );
+				}
 				else
 				{
 					const Node64* nd = nodes + node; // up to 2^32 nodes: 64-bit addressing
@@ -559,7 +605,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					node = nd->children[childIndex];												 // its pointer
 				}
 				descents++;
-				path = ( path << 3 ) | childIndex;
+				if( !TREE ) path = ( path << 3 ) | childIndex;
 				tx1 = x1; // :382-386
 				ty1 = y1;
 				tz1 = z1;
@@ -590,7 +636,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					}
 					pending &= ~bit;
 					inLds &= ~bit;
-					path >>= 3u * ( level - L );
+					if( !TREE ) path >>= 3u * ( level - L );
 					level = L;
 					node = e.x;
 					childMask = andOr( e.w >> 29, 4u, andOr( e.z >> 30, 2u, e.y >> 31 ) );
@@ -717,7 +763,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					}
 					pending &= ~bit;
 					inLds &= ~bit;
-					path >>= 3u * ( level - L );
+					if( !TREE ) path >>= 3u * ( level - L );
 					level = L;
 					node = popped.x;
 					if( !EMBED ) nodeMask = poppedMask;
@@ -755,6 +801,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
 					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
 				}
+				else if( TREE )
+				{
+					treeDescend( nodes, s.levelsM1, level, childIndex, &node, &nodeMask, &path );
+				}
 				else
 				{
 					const Node64* nd = nodes + node; // up to 2^32 nodes: 64-bit addressing
@@ -762,7 +812,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					node = nd->children[childIndex];												 // its pointer
 				}
 				descents++;
-				path = ( path << 3 ) | childIndex;
+				if( !TREE ) path = ( path << 3 ) | childIndex;
 				tx1 = mvrt_u2f( bfi( bitMask( ci, 0 ), mvrt_f2u( tx1 ), mvrt_f2u( txM ) ) ); // :382-386: upper half -> keep the exit time, else the mid-plane
 				ty1 = mvrt_u2f( bfi( bitMask( ci, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
 				tz1 = mvrt_u2f( bfi( bitMask( ci, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );

@@ -217,11 +217,12 @@ def test_config5_synthetic_8192_stress_size(mv, O):
     """BASELINE.json configs[4] at the size `bench.py --mode stress` runs: 8192^3 non-DAG octree far beyond the Infinity Cache and beyond
     the embedded-mask limit (plain 32-bit child indices, 64-bit addressing).  No oracle at this size: run-to-run determinism, geometry of
     the hit point, full-depth walks, shadow/normal agreement, vIndex range and monotonicity along a ray bundle."""
-    res, n_vox, n_rays = 8192, int(float(os.environ.get("MVRT_TEST_STRESS_VOXELS", "6.5e8"))), 2_000_000
+    res, n_vox, n_rays = 8192, int(float(os.environ.get("MVRT_TEST_STRESS_VOXELS", "1.05e9"))), 2_000_000
     svo = mv.IntersectorOctreeGPU()
     svo.build_synthetic(res, n_vox, seed=2024, flags=svo.BUILD_NO_DAG | svo.BUILD_NO_EMBEDDED_MASK)
     info = svo.info()
     assert info.levels == 13 and info.embeddedMask == 0
+    assert info.numberOfNodes * 68 > 190e9 and svo.traversal_bytes() < 100e9  # ~200 GB in the reference's layout; two-level bricks + 5 B per node here
     assert 0.97 * n_vox < info.numberOfVoxels <= n_vox and info.numberOfNodes > 2 * info.numberOfVoxels
     rng = np.random.default_rng(5)
     d = rng.normal(size=(n_rays, 3)).astype(np.float32)

@@ -106,6 +106,42 @@ def test_path_tracer_on_non_embedded_octree(mv, O):
     assert pt.stats()["rays"] == rays
 
 
+def test_path_tracer_on_tree_flavour(mv, O):
+    """the GPU builder's "tree" flavour (no DAG, masks not embedded: {mask, first child} nodes + two-level bricks, hits report the voxel index
+    directly -- no nVoxelsPSum walk) under the whole wavefront path tracer: frame buffer, ray and descent counters against the oracle on the
+    reference-layout octree the library hands back (mvrt_svo_download), which in turn equals the oracle's own non-DAG build"""
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    res, w, h = 128, 150, 85
+    sc = O.build_scene_from_triangles(tris, res, cols, emis, dag=False, embed=False)
+    rgba, hw, hh = O.decode_rgbe(hdr_bytes())
+    cam = probe_camera(sc.origin, sc.dps, res, focus=9.0, lens_r=0.05)
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    pt.loadHDRIPixels(None, rgba, hw, hh, rgba, hw, hh)
+    svo = pt.m_intersectorOctreeGPU
+    svo.build(tris.reshape(-1, 3), cols.reshape(-1, 3), emis.reshape(-1, 3), None, sc.origin, sc.dps, res, flags=svo.BUILD_NO_DAG | svo.BUILD_NO_EMBEDDED_MASK)
+    nodes, attrs, _ = svo.download()
+    got = nodes.view(O.NODE_DTYPE)
+    for f in ("mask", "children", "psum"):
+        assert np.array_equal(got[f], sc.nodes[f]), f
+    assert svo.traversal_bytes() < len(sc.nodes) * 40  # 5 B per node + a 64-byte brick for every second level
+    for _ in range(2):
+        pt.step(None, cam)
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb = np.zeros((w * h, 4), np.float32)
+    tot = dict(rays=0, descents=0, shadowDescents=0, hits=0)
+    for it in range(2):
+        fb, _, cnt = sc.render_pt(H, cam, w, h, it, math_mode=1, fb=fb, threads=8)
+        for k in tot:
+            tot[k] += cnt[k]
+    assert np.array_equal(pt.read_framebuffer()[: w * h], fb)
+    st = pt.stats()
+    for k in tot:
+        assert st[k] == tot[k], k
+
+
 @pytest.mark.parametrize("res,n,flags", [(64, 5000, 3), (256, 200_000, 1), (512, 1_000_000, 3), (128, 300_000, 0)])
 def test_synthetic_octree_matches_documented_generator(mv, O, res, n, flags):
     svo = mv.IntersectorOctreeGPU()
