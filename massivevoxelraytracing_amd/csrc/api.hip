@@ -729,8 +729,10 @@ struct mvrt_pt
 	std::vector<CameraPinhole> pendingCams;
 	int pendingIteration = 0;
 	hipStream_t pendingStream = nullptr;
+	int batchCap = MVRT_MAX_BATCH; // footprint bound (allocWork)
 	int batch = 0; // 0 = automatic: merge steps until a pass holds ~2 full-HD steps worth of samples (see effectiveBatch)
 	int depth = 3;
+	int depthWanted = 3; // what the caller asked for; `depth` may be lower when the path state would not fit (allocWork)
 	int nextSlot = 0, lastSlot = 0;
 	DevBuf statsBuf;
 	hipEvent_t forkEv = nullptr;
@@ -751,6 +753,7 @@ struct mvrt_pt
 		if( e ) depth = atoi( e );
 		if( depth < 1 ) depth = 1;
 		if( depth > 4 ) depth = 4;
+		depthWanted = depth;
 		const char* sp = getenv( "MVRT_SPLIT_SMALL" );
 		if( sp ) splitSmallPasses = atoi( sp ) != 0;
 		const char* b = getenv( "MVRT_BATCH_STEPS" );
@@ -773,6 +776,7 @@ struct mvrt_pt
 			if( b > MVRT_MAX_BATCH ) b = MVRT_MAX_BATCH;
 		}
 		while( b > 1 && perStep * b > 160000000ull ) b--;
+		if( b > batchCap ) b = batchCap; // lowered by allocWork when the path state would not fit the free HBM
 		return b;
 	}
 	// make `user` stream wait for every step that was issued on the internal streams
@@ -920,6 +924,23 @@ static int allocWork( mvrt_pt* pt )
 		MVRT_HIP( hipMemset( pt->statsBuf.p, 0, 16 * 8 ) );
 	}
 	if( !pt->forkEv ) MVRT_HIP( hipEventCreateWithFlags( &pt->forkEv, hipEventDisableTiming ) );
+	// Footprint: every in-flight pass owns ~190 bytes of path state per sample (two ping-pong path sets, ray directions, hit records, per-sample
+	// radiance) -- depth x batch x ownedPixels x 16 x 190 B, e.g. 3 x 2 x 6.3 GB at 1920x1080 (the reference: a fixed 1.24 GB stack slab).  It
+	// must fit beside the octree: when it would take more than 70 % of the HBM that is free right now, merge fewer steps per pass first, then
+	// keep fewer passes in flight.  Results do not depend on either.
+	{
+		for( mvrt_pt::Slot& sl : pt->slots ) sl.work.release(); // (what is allocated now is about to be replaced)
+		size_t freeB = 0, totalB = 0;
+		MVRT_HIP( hipMemGetInfo( &freeB, &totalB ) );
+		pt->batchCap = MVRT_MAX_BATCH;
+		pt->depth = pt->depthWanted;
+		const uint64_t budget = (uint64_t)( 0.7 * (double)freeB );
+		auto need = [&]() { return (uint64_t)pt->depth * pt->ownedPixels * MVRT_SPP_PER_STEP * (uint64_t)pt->effectiveBatch() * 190ull; };
+		while( need() > budget && pt->effectiveBatch() > 1 ) pt->batchCap = pt->effectiveBatch() - 1;
+		while( need() > budget && pt->depth > 1 ) pt->depth--;
+		REQUIRE( need() <= budget, "frame of %llu owned pixels needs %.1f GB of path state, %.1f GB of HBM are free (split the frame into tiles: mvrt_pt_set_tile)",
+				 (unsigned long long)pt->ownedPixels, need() / 1e9, freeB / 1e9 );
+	}
 	for( int i = 0; i < 4; i++ )
 	{
 		mvrt_pt::Slot& sl = pt->slots[i];
@@ -1254,7 +1275,7 @@ MVRT_EXPORT int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth )
 {
 	REQUIRE( pt && depth >= 1 && depth <= 4, "pipeline depth must be 1..4" );
 	if( pt->drain() ) return 1;
-	pt->depth = depth;
+	pt->depth = pt->depthWanted = depth;
 	if( pt->fbF32.p ) return allocWork( pt );
 	return 0;
 }
