@@ -157,22 +157,51 @@ def test_render_normals_bytesum(bunny256):
     assert int(r["rgba"].astype(np.uint64).sum()) == G["render_normals_256x144_bytesum"]
 
 
+def survey_probe_rays(cam, W, H):
+    """Pixel-centre rays the way the survey's probe driver evaluated the CameraPinhole::shoot formula (renderCommon.hpp:37-49): the scalar
+    mix(-tan, tan, xf) * W / H first, then right * that.  The reference's own expression associates the other way -- (m_right * mix) * W / H,
+    component by component -- which moves one edge pixel of the 1024^3 frame; with THIS association the oracle reproduces every Appendix-A
+    number of both resolutions exactly."""
+    f32 = np.float32
+    o, front, up, right, tan_h = cam[0:3], cam[3:6], cam[6:9], cam[9:12], cam[12]
+    xs = ((np.arange(W, dtype=f32) + f32(0.5)) / f32(W)).astype(f32)
+    ys = ((np.arange(H, dtype=f32) + f32(0.5)) / f32(H)).astype(f32)
+    mx = (-tan_h + f32(tan_h - (-tan_h)) * xs).astype(f32)
+    my = (tan_h + f32(-tan_h - tan_h) * ys).astype(f32)
+    mx = (mx * f32(W) / f32(H)).astype(f32)
+    rd = ((right[None, None, :] * mx[None, :, None]).astype(f32) + (up[None, None, :] * my[:, None, None]).astype(f32)).astype(f32)
+    rd = (rd + front[None, None, :]).astype(f32).reshape(-1, 3)
+    return np.tile(o, (W * H, 1)).astype(f32), rd
+
+
+def _primary_stats(r):
+    hit = r["t"] != O.MAX_FLOAT
+    nm = r["nMajor"][hit]
+    return int(hit.sum()), [int((nm == k).sum()) for k in (0, 1, 2)], int(r["vIndex"][hit].astype(np.uint64).sum())
+
+
 def test_bunny1024_counts_and_hits():
-    """1024^3: voxel/node counts and hit count are exact; the nMajor split and sum(vIndex) sit within
-    +-1 of the survey's numbers (one edge pixel; the survey's probe driver was compiled with
-    clang's default contraction for the camera arithmetic, ours is contraction-free)."""
+    """1024^3: voxel / node counts exact; the 2 073 600 probe rays reproduce the survey's hit count, nMajor split and sum(vIndex) EXACTLY when the
+    shoot formula is evaluated the way the survey's probe driver did (survey_probe_rays); with the reference's own association of the same
+    formula (the oracle's render_primary, = what the product's render kernel implements) one edge pixel differs."""
     g = G["bunny"]["1024"]
     sc = O.build_scene_from_triangles(bunny_tris(), 1024)
     assert (sc.dumped, len(sc.morton), len(sc.nodes)) == (g["dumped"], g["voxels"], g["dag_nodes"])
     cam = probe_camera(sc.origin, sc.dps, 1024)
+    ro, rd = survey_probe_rays(cam, 1920, 1080)
+    hits, split, sv = _primary_stats(sc.trace(ro, rd, threads=8))
+    assert (hits, split, sv) == (g["primary_1080p"]["hits"], g["primary_1080p"]["nMajor_z_x_y"], g["primary_1080p"]["sum_vIndex"])
     r = sc.render_primary(cam, 1920, 1080, threads=8)
-    hit = r["t"] != O.MAX_FLOAT
-    nm = r["nMajor"][hit]
-    assert int(hit.sum()) == g["primary_1080p"]["hits"]
-    got = [int((nm == k).sum()) for k in (0, 1, 2)]
-    assert max(abs(a - b) for a, b in zip(got, g["primary_1080p"]["nMajor_z_x_y"])) <= 1
-    assert abs(int(r["vIndex"][hit].astype(np.uint64).sum()) - g["primary_1080p"]["sum_vIndex"]) <= 2
+    hits2, split2, sv2 = _primary_stats(r)
+    assert hits2 == hits and max(abs(a - b) for a, b in zip(split2, split)) <= 1 and abs(sv2 - sv) <= 2
     assert abs(float(r["descents"].mean()) - g["primary_1080p"]["mean_descents_all_pixels"]) < 0.05
+
+
+def test_bunny256_survey_probe_rays_also_exact(bunny256):
+    g = G["bunny"]["256"]["primary_1080p"]
+    cam = probe_camera(bunny256.origin, bunny256.dps, 256)
+    ro, rd = survey_probe_rays(cam, 1920, 1080)
+    assert _primary_stats(bunny256.trace(ro, rd, threads=8)) == (g["hits"], g["nMajor_z_x_y"], g["sum_vIndex"])
 
 
 def test_hdri_sat_golden():
