@@ -142,6 +142,7 @@ struct mvrt_svo
 	uint32_t treeLevelBase[24] = { 0 }, treeLevelCount[24] = { 0 };
 	uint2* attrs = nullptr;
 	uint64_t* morton = nullptr; // only after build()
+	DevBuf kids;				// embedded flavour: children[8] per node, 32 B per node (what the traversal reads)
 	DevBuf topTable;			// per-prefix start of the nVoxelsPSum walk (SvoDev::topTable), embedded flavour
 	uint32_t topLevels = 0;
 	mutable DevBuf wsBuf;		// traversal workspace (spill rows + cursor), sized on demand
@@ -171,6 +172,7 @@ struct mvrt_svo
 		attrs = nullptr;
 		morton = nullptr;
 		topTable.release();
+		kids.release();
 		topLevels = 0;
 		float es = info.emissionScale;
 		memset( &info, 0, sizeof( info ) );
@@ -215,6 +217,7 @@ struct mvrt_svo
 		d.levels = info.levels;
 		d.rootIndex = info.numberOfNodes - 1; // root = last node, :250
 		d.rootMask = rootMask;
+		d.kids = kids.as<uint32_t>();
 		d.topTable = topTable.as<uint2>();
 		d.topLevels = topLevels;
 		d.tree = tree;
@@ -234,8 +237,11 @@ static int ownerDrain( const mvrt_svo* s ) { return s && s->owner ? ptDrain( s->
 static int buildTopTable( mvrt_svo* s, hipStream_t st )
 {
 	s->topTable.release();
+	s->kids.release();
 	s->topLevels = 0;
 	if( !s->info.embeddedMask || !s->nodes || s->info.levels == 0 ) return 0;
+	if( s->kids.alloc( (uint64_t)s->info.numberOfNodes * 32 ) ) return 1;
+	if( launchCopyKids( s->nodes, s->info.numberOfNodes, s->kids.as<uint32_t>(), st ) ) return 1;
 	static const int envK = getenv( "MVRT_TOP_LEVELS" ) ? atoi( getenv( "MVRT_TOP_LEVELS" ) ) : 7;
 	uint32_t k = (uint32_t)( envK < 0 ? 0 : ( envK > 8 ? 8 : envK ) );
 	if( k > s->info.levels ) k = s->info.levels;
@@ -375,7 +381,7 @@ MVRT_EXPORT uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo )
 	if( !svo || !svo->nodes ) return 0;
 	const uint64_t n = svo->info.numberOfNodes;
 	if( svo->tree ) return (uint64_t)svo->nBricks * sizeof( Node64 ) + n * 5;
-	return n * sizeof( Node64 ) + n + ( svo->psumCold ? n * 32 : 0 ) + svo->topTable.bytes;
+	return n * sizeof( Node64 ) + n + ( svo->psumCold ? n * 32 : 0 ) + svo->topTable.bytes + svo->kids.bytes;
 }
 MVRT_EXPORT const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->nodes : nullptr; }
 MVRT_EXPORT const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->attrs : nullptr; }

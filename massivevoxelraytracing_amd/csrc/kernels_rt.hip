@@ -76,8 +76,8 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
-	__shared__ uint4 ring[MVRT_RING * 64];
-	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING * 64];
+	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
 	traceStream<FL>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask, ws.spillMask );
 }
 
@@ -125,8 +125,8 @@ struct PrimaryIO
 template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
-	__shared__ uint4 ring[MVRT_RING * 64];
-	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING * 64];
+	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
 	traceStream<FL>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
 						ws.spillMask );
 }
@@ -666,8 +666,8 @@ template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk,
 																			uint32_t raysPerLane, uint32_t minWaves )
 {
-	__shared__ uint4 ring[MVRT_RING * 64];
-	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING * 64];
+	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
 	PtIO io;
 	io.table = P.buf.selfDev;
 	io.setIdx = setIdx;

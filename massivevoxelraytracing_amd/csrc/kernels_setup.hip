@@ -139,6 +139,16 @@ __global__ void __launch_bounds__( 256 ) kBuildTopTable( const Node64* __restric
 		table[p] = alive ? make_uint2( n, v ) : make_uint2( 0u, 0u );
 	}
 }
+__global__ void __launch_bounds__( 256 ) kCopyKids( const Node64* __restrict__ nodes, uint64_t nNodes, uint32_t* __restrict__ kids )
+{
+	for( uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < nNodes * 8; g += (uint64_t)gridDim.x * 256 ) kids[g] = nodes[g / 8].children[g % 8];
+}
+int launchCopyKids( const Node64* nodes, uint64_t nNodes, uint32_t* kids, hipStream_t stream )
+{
+	hipLaunchKernelGGL( kCopyKids, dim3( cappedGrid( nNodes * 8 ) ), dim3( 256 ), 0, stream, nodes, nNodes, kids );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream )
 {
 	hipLaunchKernelGGL( kBuildTopTable, dim3( cappedGrid( 1ull << ( 3 * k ) ) ), dim3( 256 ), 0, stream, nodes, rootIndex, k, table );

@@ -92,6 +92,7 @@ int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, ui
 // tree flavour -> the reference's 68-byte nodes (mask, children[8], nVoxelsPSum[8]) from { mask, first child } per node
 int launchTreeTo68( const uint8_t* masks, const uint32_t* first, const uint32_t* levelBase, const uint32_t* levelCount, int levels, uint32_t nNodes, uint32_t nVoxels, uint8_t* nodes68,
 					hipStream_t stream );
+int launchCopyKids( const Node64* nodes, uint64_t nNodes, uint32_t* kids, hipStream_t stream ); // embedded flavour: compact children array for the traversal
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream ); // embedded flavour only
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 

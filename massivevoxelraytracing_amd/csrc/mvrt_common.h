@@ -173,6 +173,7 @@ struct SvoDev
 	// embedded flavour: what the first topLevels levels of the nVoxelsPSum walk add up to, per path prefix: topTable[prefix] = { node reached
 	// (index), sum of nVoxelsPSum along the prefix }.  The top of a DAG is a tree (sharing starts near the leaves), the table is per PATH, so it
 	// is exact either way; entries of prefixes that leave the octree are never looked up (only paths of real hits are resolved).
+	const uint32_t* kids; // embedded flavour: children[8] per node, 32 B per node -- what the traversal reads (nodes[] keeps the full lines for the psum walk)
 	const uint2* topTable;
 	uint32_t topLevels; // 0 = no table
 	// tree flavour (svo_build.hip): `nodes` are two-level bricks, treeRoot is where the traversal starts (a brick index, or a voxel index for a

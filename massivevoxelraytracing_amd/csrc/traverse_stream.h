@@ -41,7 +41,7 @@
 //        the CONSUMER of the hit sums nVoxelsPSum along it (voxelIndexFromPath) in a dense kernel where
 //        all 64 lanes walk together.  This also removes the nVoxelsPSum load from every descent.
 //    An entry is {child reference (index | mask << 24), tx1, ty1, tz1} = one ds_write_b128.
-//  * 4-slot LDS ring per lane (slot = level & 3) = 4 KiB per wave, so 32 waves fit a CU's 160 KiB.
+//  * LDS ring per lane (slot = level & (slots - 1); 8 slots = 8 KiB per wave for the embedded flavour, 4 for the others, see MVRT_RING_OF).
 //    A push that lands on an occupied slot first evicts that (shallower) entry to an HBM spill array
 //    laid out [level][lane] (coalesced 1 KiB rows); a pop of an evicted level reads it back.  Hot
 //    pushes and pops near the leaves never leave LDS.
@@ -52,10 +52,13 @@
 #pragma once
 #include "mvrt_common.h"
 
-#ifndef MVRT_RING
-#define MVRT_RING 4 // LDS ring slots per lane (4 or 8)
+// LDS ring slots per lane: 8 for the embedded flavour (cache-resident DAG octrees: 5 to 7 resident waves per SIMD perform alike, fewer
+// evictions to the HBM spill rows are worth +1.5 %), 4 for the flavours that walk HBM-resident octrees (every resident wave counts there, and
+// they carry a second ring for the node masks)
+#ifndef MVRT_RING_EMBED
+#define MVRT_RING_EMBED 8
 #endif
-#define MVRT_RING_CLASH ( MVRT_RING == 4 ? 0x11111111u : 0x01010101u ) // the levels that share ring slot 0
+#define MVRT_RING_OF( FL ) ( ( FL ) == 0 ? MVRT_RING_EMBED : 4 )
 #ifndef MVRT_REFILL_MIN
 #define MVRT_REFILL_MIN 20 // refill once this many lanes are idle (or all of them)
 #endif
@@ -104,6 +107,7 @@ MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 struct TraceCore
 {
 	const Node64* nodes;
+	const uint32_t* kids; // embedded flavour: children[8] of every node, 32 bytes per node (the traversal never reads nVoxelsPSum: half the cache footprint)
 	float lox, loy, loz, hix, hiy, hiz;
 	uint32_t rootRef; // rootIndex | rootMask << 24 (voxCommon.hpp:306)
 	uint32_t rootIndex, rootMask;
@@ -113,6 +117,7 @@ MVRT_HDI TraceCore makeTraceCore( const SvoDev& s )
 {
 	TraceCore c;
 	c.nodes = s.nodes;
+	c.kids = s.kids;
 	c.lox = s.lower.x; c.loy = s.lower.y; c.loz = s.lower.z;
 	c.hix = s.upper.x; c.hiy = s.upper.y; c.hiz = s.upper.z;
 	c.rootRef = s.rootIndex | ( s.rootMask << 24 );
@@ -275,7 +280,7 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 				}
 				if( EMBED )
 				{
-					node = s.nodes[node & 0xFFFFFFu].children[childIndex];
+					node = s.kids[( node & 0xFFFFFFu ) * 8u + childIndex];
 				}
 				else if( TREE )
 				{
@@ -333,14 +338,17 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 // every active lane: straight-line bit arithmetic (v_bfi / v_bfe selects instead of compare-select chains)
 // followed by three shallow branches: descend (with push), pop, hit.
 template <int FL, class IO>
-MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING][64] */,
+MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned long long* __restrict__ cursor, uint32_t chunk, uint4* __restrict__ ldsRing /* [MVRT_RING_OF( FL )][64] */,
 						  uint4* __restrict__ spill /* [levels][spillStride] */, uint64_t spillStride, uint64_t spillLane, uint32_t* __restrict__ ldsMask = nullptr /* [MVRT_RING][64], !EMBED */,
 						  uint32_t* __restrict__ spillMask = nullptr /* [levels][spillStride], !EMBED */ )
 {
 	constexpr bool EMBED = FL == 0, TREE = FL == 2;
+	constexpr uint32_t MVRT_RING = MVRT_RING_OF( FL );
+	constexpr uint32_t MVRT_RING_CLASH = MVRT_RING == 4 ? 0x11111111u : 0x01010101u; // the levels that share ring slot 0
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = (uint32_t)total64;
 	const Node64* __restrict__ nodes = s.nodes;
+	const uint32_t* __restrict__ kids = s.kids;
 	// LDS ring: explicit LDS address space (so the optimiser cannot fold a ring read and a spill read into one flat
 	// load); slot k of this lane at byte offset k * 1024 + lane * 16
 	LdsU4* const myRing = (LdsU4*)ldsRing + lane;
@@ -592,7 +600,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				if( EMBED )
 				{
 					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
-					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
+					node = *(const uint32_t*)( (const char*)kids + ( ( ( node & 0xFFFFFFu ) << 5 ) | ( childIndex << 2 ) ) );
 				}
 				else if( TREE )
 				{
@@ -799,7 +807,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				if( EMBED )
 				{
 					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
-					node = *(const uint32_t*)( (const char*)nodes + ( ( ( node & 0xFFFFFFu ) << 6 ) | ( childIndex << 2 ) ) );
+					node = *(const uint32_t*)( (const char*)kids + ( ( ( node & 0xFFFFFFu ) << 5 ) | ( childIndex << 2 ) ) );
 				}
 				else if( TREE )
 				{
