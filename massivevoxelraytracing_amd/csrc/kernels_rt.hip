@@ -73,8 +73,10 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 #ifndef MVRT_TRACE_WAVES
 #define MVRT_TRACE_WAVES 7 // waves per SIMD the traversal kernels are register-budgeted for (72 VGPRs)
 #endif
+// the embedded flavour's 8 KiB LDS ring admits 5 waves per SIMD (5, 6 and 7 perform alike on cache-resident octrees, profiles/r02_traversal_experiments.txt)
+#define MVRT_WAVES_OF( FL ) ( ( FL ) == 0 && MVRT_RING_EMBED == 8 && MVRT_TRACE_WAVES > 5 ? 5 : MVRT_TRACE_WAVES )
 template <int FL>
-__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
+__global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
 	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
@@ -123,7 +125,7 @@ struct PrimaryIO
 	}
 };
 template <int FL>
-__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
+__global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
 	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
@@ -663,7 +665,7 @@ struct PtIO
 	}
 };
 template <int FL>
-__global__ void __launch_bounds__( 64, MVRT_TRACE_WAVES ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk,
+__global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kPtTraceStream( PtParams P, TraceWorkspace ws, int stage, int setIdx, int nKinds, int shadowKind, uint32_t chunk,
 																			uint32_t raysPerLane, uint32_t minWaves )
 {
 	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];

@@ -133,7 +133,7 @@ def test_render_vertex_colors(mv, O, bunny256_color):
     assert_hits_equal(want, got)
 
 
-@pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 257, 1000, 65536, 1_000_003])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 257, 1000, 1023, 1024, 1025, 65536, 1_000_003, 1_048_576, 1_048_577, 5_000_011])  # (> 4096 blocks: several scan tiles)
 def test_compaction_indices_bit_exact(mv, O, n):
     rng = np.random.default_rng(n)
     for density in (0.0, 0.13, 0.9, 1.0):
