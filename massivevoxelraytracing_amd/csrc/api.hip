@@ -882,9 +882,9 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
 	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP * pt->effectiveBatch();
 	const uint64_t nBlocks = cap / 256 + 8; // (+ padding: the scan reads whole 16-byte quads)
-	// 2 path sets x 16 arrays + 6 direction arrays + hitT,hitV,hitEV + 3 sample-radiance arrays + 2 x 8-byte path arrays,
+	// 2 path sets x 16 arrays + 6 direction arrays + hitT + 3 sample-radiance arrays + 2 x 8-byte path arrays,
 	// 4 bytes per word; 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
-	const uint64_t words = cap * ( 32 + 6 + 3 + 3 + 4 );
+	const uint64_t words = cap * ( 32 + 6 + 1 + 3 + 4 );
 	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 1024 + 64 * 256;
 	if( sl.work.alloc( bytes ) ) return 1;
 	uint8_t* base = (uint8_t*)sl.work.p;
@@ -906,8 +906,6 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	for( float** q : d ) *q = (float*)take( cap * 4 );
 	b.hitPath = (uint64_t*)take( cap * 8 );
 	b.hitEPath = (uint64_t*)take( cap * 8 );
-	b.hitV = (uint32_t*)take( cap * 4 );
-	b.hitEV = (uint32_t*)take( cap * 4 );
 	b.hitN = (uint8_t*)take( cap );
 	b.hitS = (uint8_t*)take( cap );
 	b.hitE = (uint8_t*)take( cap );

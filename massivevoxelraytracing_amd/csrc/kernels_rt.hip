@@ -6,12 +6,10 @@
 #include <stdlib.h>
 
 #include "launch.h"
-#include "traverse.h"
 #include "traverse_stream.h"
 
 #define WAVE 64
 #define CBLOCK 256 // paths per compaction block
-#define TRACE_BLOCK 64 // one wavefront per workgroup: no barriers, LDS granule = one wave's stack
 
 MVRT_DI uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi( ~0u, __builtin_amdgcn_mbcnt_lo( ~0u, 0u ) ); }
 
@@ -163,43 +161,6 @@ uint64_t traceWorkspaceLanes()
 // =====================================================================================================
 // mvrt_trace_batch: host-callable batch form of IntersectorOctreeGPU::intersect
 // =====================================================================================================
-__global__ void __launch_bounds__( TRACE_BLOCK ) kTraceBatch( SvoDev svo, uint64_t n, const float* __restrict__ rox, const float* __restrict__ roy,
-															   const float* __restrict__ roz, const float* __restrict__ rdx, const float* __restrict__ rdy,
-															   const float* __restrict__ rdz, const uint8_t* __restrict__ isShadow, float* __restrict__ tOut,
-															   int32_t* __restrict__ nMajorOut, uint32_t* __restrict__ vIndexOut, uint32_t* __restrict__ descentsOut )
-{
-	extern __shared__ uint32_t lds[];
-	const uint32_t lane = threadIdx.x;
-	for( uint64_t base = (uint64_t)blockIdx.x * TRACE_BLOCK; base < n; base += (uint64_t)gridDim.x * TRACE_BLOCK )
-	{
-		uint64_t i = base + lane;
-		if( i < n )
-		{
-			f3 ro = mk3( rox[i], roy[i], roz[i] );
-			f3 rd = mk3( rdx[i], rdy[i], rdz[i] );
-			bool sh = isShadow ? isShadow[i] != 0 : false;
-			TraceResult r = traceRay<true>( svo, ro, rd, sh, lds, TRACE_BLOCK, lane );
-			tOut[i] = r.t;
-			if( nMajorOut ) nMajorOut[i] = r.nMajor;
-			if( vIndexOut ) vIndexOut[i] = r.vIndex;
-			if( descentsOut ) descentsOut[i] = r.descents;
-		}
-	}
-}
-
-static size_t traceLdsBytes( const SvoDev& svo, int block )
-{
-	uint32_t slots = svo.levels < 1 ? 1 : svo.levels;
-	static int pad = -1; // MVRT_LDS_PAD_SLOTS: occupancy experiments only (extra, unused stack slots)
-	if( pad < 0 )
-	{
-		const char* e = getenv( "MVRT_LDS_PAD_SLOTS" );
-		pad = e ? atoi( e ) : 0;
-	}
-	slots += pad;
-	return (size_t)slots * MVRT_STACK_FIELDS * block * sizeof( uint32_t );
-}
-
 static int persistentGrid( uint64_t items, int block, int numCUs, int blocksPerCU )
 {
 	uint64_t need = ( items + block - 1 ) / block;
@@ -219,16 +180,6 @@ static int numCUs()
 		if( g_numCUs <= 0 ) g_numCUs = 256;
 	}
 	return g_numCUs;
-}
-
-template <class K>
-static int allowLds( K kernel, size_t bytes )
-{
-	if( bytes > 64 * 1024 )
-	{
-		MVRT_HIP( hipFuncSetAttribute( (const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes ) );
-	}
-	return 0;
 }
 
 int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy,
@@ -254,58 +205,13 @@ int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, c
 		MVRT_HIP( hipGetLastError() );
 		return 0;
 	}
-	size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
-	if( allowLds( kTraceBatch, lds ) ) return 1;
-	int grid = persistentGrid( n, TRACE_BLOCK, numCUs(), 32 );
-	hipLaunchKernelGGL( kTraceBatch, dim3( grid ), dim3( TRACE_BLOCK ), lds, stream, svo, n, rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, vIndex, descents );
-	MVRT_HIP( hipGetLastError() );
-	return 0;
+	mvrtSetError( "internal: traversal workspace missing" );
+	return 1;
 }
 
 // =====================================================================================================
 // mvrt_render_primary: the `render` kernel (voxKernel.cu:437-483)
 // =====================================================================================================
-__global__ void __launch_bounds__( TRACE_BLOCK ) kRenderPrimary( SvoDev svo, CameraPinhole cam, int W, int H, int showVertexColor, uchar4* __restrict__ rgba,
-																  float* __restrict__ tOut, int32_t* __restrict__ nMajorOut, uint32_t* __restrict__ vIndexOut,
-																  uint32_t* __restrict__ descentsOut )
-{
-	extern __shared__ uint32_t lds[];
-	const uint32_t lane = threadIdx.x;
-	const uint64_t n = (uint64_t)W * H;
-	for( uint64_t base = (uint64_t)blockIdx.x * TRACE_BLOCK; base < n; base += (uint64_t)gridDim.x * TRACE_BLOCK )
-	{
-		uint64_t pixelIdx = base + lane;
-		if( pixelIdx < n )
-		{
-			int x = (int)( pixelIdx % W );
-			int y = (int)( pixelIdx / W );
-			f3 ro, rd;
-			cameraShoot( cam, &ro, &rd, x, y, 0.5f, 0.5f, W, H );
-			TraceResult r = traceRay<true>( svo, ro, rd, false, lds, TRACE_BLOCK, lane );
-			uchar4 c = make_uchar4( 0, 0, 0, 255 );
-			if( r.t != MVRT_MAXF )
-			{
-				if( showVertexColor )
-				{
-					uint32_t col = svo.attrs[r.vIndex].x;
-					c = make_uchar4( col & 0xFF, ( col >> 8 ) & 0xFF, ( col >> 16 ) & 0xFF, ( col >> 24 ) & 0xFF );
-				}
-				else
-				{
-					f3 hn = getHitN( r.nMajor, rd );
-					f3 color = ( hn + mk3( 1.0f, 1.0f, 1.0f ) ) * 0.5f;
-					c = make_uchar4( (uint8_t)( 255 * color.x + 0.5f ), (uint8_t)( 255 * color.y + 0.5f ), (uint8_t)( 255 * color.z + 0.5f ), 255 );
-				}
-			}
-			if( rgba ) rgba[pixelIdx] = c;
-			if( tOut ) tOut[pixelIdx] = r.t;
-			if( nMajorOut ) nMajorOut[pixelIdx] = r.nMajor;
-			if( vIndexOut ) vIndexOut[pixelIdx] = r.vIndex;
-			if( descentsOut ) descentsOut[pixelIdx] = r.descents;
-		}
-	}
-}
-
 int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t,
 						 int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
 {
@@ -342,12 +248,8 @@ int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const Came
 		MVRT_HIP( hipGetLastError() );
 		return 0;
 	}
-	size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
-	if( allowLds( kRenderPrimary, lds ) ) return 1;
-	int grid = persistentGrid( n, TRACE_BLOCK, numCUs(), 32 );
-	hipLaunchKernelGGL( kRenderPrimary, dim3( grid ), dim3( TRACE_BLOCK ), lds, stream, svo, cam, W, H, showVertexColor, rgba, t, nMajor, vIndex, descents );
-	MVRT_HIP( hipGetLastError() );
-	return 0;
+	mvrtSetError( "internal: traversal workspace missing" );
+	return 1;
 }
 
 // =====================================================================================================
@@ -479,7 +381,6 @@ struct PtParams
 	PtBuffers buf;
 	int hdriEnabled;  // hdri.isEnabled(), renderCommon.hpp:467-470
 	int extraSamples; // nSampleExtraDirect = hasEmission ? 1 : 0, voxKernel.cu:721
-	int usePaths;	  // hits carry voxel paths (persistent traversal) instead of vIndex (plain traversal)
 };
 
 // owned (local) pixel -> global pixel index.  Blocks of 256 pixels dealt round-robin over tiles.
@@ -538,64 +439,6 @@ __global__ void __launch_bounds__( 256 ) kPtGenerate( PtParams P )
 }
 
 // ---- trace: all rays of one stage.  Ray r = kind * n + path; kind 0 bounce/primary, 1 shadow, 2 extra -
-__global__ void __launch_bounds__( TRACE_BLOCK ) kPtTrace( PtParams P, int stage, int setIdx, int nKinds, int shadowKind, int extraKind )
-{
-	extern __shared__ uint32_t lds[];
-	const uint32_t lane = threadIdx.x;
-	const uint64_t n = P.buf.liveCount[stage];
-	const uint64_t total = n * nKinds;
-	const PathSet& in = P.buf.set[setIdx];
-	unsigned long long dNormal = 0, dShadow = 0, nHits = 0;
-	for( uint64_t base = (uint64_t)blockIdx.x * TRACE_BLOCK; base < total; base += (uint64_t)gridDim.x * TRACE_BLOCK )
-	{
-		uint64_t r = base + lane;
-		if( r < total )
-		{
-			int kindSlot = ( r >= n ) + ( r >= 2 * n );
-			uint64_t i = r - (uint64_t)kindSlot * n;
-			int kind = kindSlot == 0 ? 0 : ( kindSlot == 1 ? ( shadowKind ? 1 : 2 ) : 2 );
-			f3 ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
-			f3 rd;
-			if( kind == 0 ) rd = mk3( in.rdx[i], in.rdy[i], in.rdz[i] );
-			else if( kind == 1 ) rd = mk3( P.buf.sx[i], P.buf.sy[i], P.buf.sz[i] );
-			else rd = mk3( P.buf.ex[i], P.buf.ey[i], P.buf.ez[i] );
-			TraceResult h = traceRay<true>( P.svo, ro, rd, kind == 1, lds, TRACE_BLOCK, lane );
-			if( kind == 0 )
-			{
-				P.buf.hitT[i] = h.t;
-				P.buf.hitV[i] = h.vIndex;
-				P.buf.hitN[i] = (uint8_t)h.nMajor;
-				if( h.t != MVRT_MAXF ) atomicAdd( &P.buf.blockCount[i / CBLOCK], 1u );
-			}
-			else if( kind == 1 )
-			{
-				P.buf.hitS[i] = h.t != MVRT_MAXF ? 1 : 0;
-			}
-			else
-			{
-				P.buf.hitE[i] = h.t != MVRT_MAXF ? 1 : 0;
-				P.buf.hitEV[i] = h.vIndex;
-			}
-			if( kind == 1 ) dShadow += h.descents;
-			else
-			{
-				dNormal += h.descents;
-				nHits += h.t != MVRT_MAXF ? 1 : 0;
-			}
-		}
-	}
-	(void)extraKind;
-	dNormal = waveSum( dNormal );
-	dShadow = waveSum( dShadow );
-	nHits = waveSum( nHits );
-	if( lane == 0 )
-	{
-		if( dNormal ) atomicAdd( &P.buf.stats[2], dNormal );
-		if( dShadow ) atomicAdd( &P.buf.stats[3], dShadow );
-		if( nHits ) atomicAdd( &P.buf.stats[4], nHits );
-	}
-}
-
 // Opaque view of a kernarg pointer: the asm makes the value unknown to the optimiser at this point, so the ~25 array
 // pointers read through it are (re)loaded with scalar loads where they are used -- at refill time -- instead of being
 // hoisted out of the traversal loop, where they would occupy ~60 SGPRs and push the node pointer out of registers.
@@ -844,7 +687,7 @@ __global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int
 			nMajor = P.buf.hitN[i];
 			const bool hit = t != MVRT_MAXF;
 			// the persistent traversal reports the hit voxel's path; its index is summed here, all lanes together
-			vIndex = P.usePaths ? ( hit ? voxelIndexFromPath( P.svo, P.buf.hitPath[i] ) : 0u ) : P.buf.hitV[i];
+			vIndex = hit ? voxelIndexFromPath( P.svo, P.buf.hitPath[i] ) : 0u;
 			if( stage == 0 )
 			{
 				T = mk3( 1.0f, 1.0f, 1.0f );
@@ -870,7 +713,7 @@ __global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int
 				{
 					if( P.buf.hitE[i] )
 					{
-						const uint32_t ev = P.usePaths ? voxelIndexFromPath( P.svo, P.buf.hitEPath[i] ) : P.buf.hitEV[i];
+						const uint32_t ev = voxelIndexFromPath( P.svo, P.buf.hitEPath[i] );
 						f3 Le = voxelEmission( P.svo, ev, true );
 						L = L + T * Le / (float)( 1 + P.extraSamples );
 					}
@@ -994,7 +837,6 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 	P.buf = buf;
 	P.hdriEnabled = ( 0.0f < hdri.scale ) ? 1 : 0;
 	P.extraSamples = svo.hasEmission ? 1 : 0;
-	P.usePaths = ws.spill ? 1 : 0;
 	if( nCUs <= 0 ) nCUs = numCUs();
 
 	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP * frame.nSteps;
@@ -1009,8 +851,11 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		mvrtSetError( "path buffers too small: %llu samples > capacity %llu", (unsigned long long)nSamples, (unsigned long long)buf.cap );
 		return 1;
 	}
-	const size_t lds = traceLdsBytes( svo, TRACE_BLOCK );
-	if( allowLds( kPtTrace, lds ) ) return 1;
+	if( !ws.spill )
+	{
+		mvrtSetError( "internal: traversal workspace missing" );
+		return 1;
+	}
 
 #define PROF_BEGIN( c ) if( prof ) prof->begin( c, stream )
 #define PROF_END() if( prof ) prof->end( stream )
@@ -1025,10 +870,7 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		const int shadowKind = ( stage > 0 && P.hdriEnabled ) ? 1 : 0;
 		const int extraKind = ( stage == 1 && P.extraSamples ) ? 1 : 0;
 		const int nKinds = 1 + shadowKind + extraKind;
-		// upper bound for the grid: every stage has at most nSamples live paths
-		const int traceGrid = persistentGrid( nSamples * nKinds, TRACE_BLOCK, nCUs, 32 );
 		PROF_BEGIN( MVRT_K_TRACE );
-		if( ws.spill )
 		{
 			int g = streamGrid( nSamples * nKinds, nCUs );
 			uint32_t smallRpl = 0, smallMinW = 0;
@@ -1055,10 +897,6 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 				hipLaunchKernelGGL( kPtTraceStream<2>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
 			else
 				hipLaunchKernelGGL( kPtTraceStream<1>, dim3( g ), dim3( 64 ), 0, stream, P, ws, stage, setIdx, nKinds, shadowKind, streamChunk( nSamples * nKinds, g ), smallRpl, smallMinW );
-		}
-		else
-		{
-			hipLaunchKernelGGL( kPtTrace, dim3( traceGrid ), dim3( TRACE_BLOCK ), lds, stream, P, stage, setIdx, nKinds, shadowKind, extraKind );
 		}
 		PROF_END();
 		PROF_BEGIN( MVRT_K_OTHER );

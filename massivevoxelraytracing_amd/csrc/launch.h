@@ -19,11 +19,9 @@ struct PtBuffers
 	float *ex, *ey, *ez; // extra Lambert ray direction (kind 2, stage 1 only), origin = ro
 	// hit records written by the traversal kernel, one array per ray kind
 	float* hitT;	  // kind 0: t (MAX_FLOAT = miss)
-	uint32_t* hitV;	  // kind 0: vIndex
 	uint8_t* hitN;	  // kind 0: nMajor
 	uint8_t* hitS;	  // kind 1: 1 if the shadow ray is occluded
 	uint8_t* hitE;	  // kind 2: 1 if the extra ray hit
-	uint32_t* hitEV;  // kind 2: vIndex
 	uint64_t* hitPath;	// kind 0: voxel path (persistent traversal; vIndex is derived by the shade kernel)
 	uint64_t* hitEPath; // kind 2: voxel path
 	float *Lsx, *Lsy, *Lsz; // final radiance per sample, indexed by task (read by accumulate)

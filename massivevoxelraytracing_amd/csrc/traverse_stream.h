@@ -17,7 +17,7 @@
 //                   voxelIndexFromPath reads), so a descent is ONE line fetch, exactly like the embedded flavour; the
 //                   node mask travels in a fifth stack dword.
 //
-// Same results as traverse.h / the reference's octreeTraverse_EfficientParametric
+// Same results as the reference's octreeTraverse_EfficientParametric
 // (voxCommon.hpp:231-423): identical slab arithmetic, child order, tie-breaks and hit test.  What is
 // different is everything the hardware cares about.  Measured on MI355X (DESIGN.md 5.3,
 // profiles/r01_gfx950_issue_and_gather_costs.txt): on cache-resident DAG octrees the step is bound by instruction
