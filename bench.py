@@ -233,7 +233,7 @@ def main():
     # ---- the non-overlapped pass the roofline comes from: pipeline depth 1, one step per pass, no sibling passes, HIP events around every
     # kernel on the one stream everything runs on.  Kernel times cannot overlap, so sum(kernel ms) <= wall time of this pass. ----
     serial = None
-    if (not args.no_serial_pass and world == 1 and not args.emulate_tiles) or args.serial_only:
+    if (not args.no_serial_pass and not args.emulate_tiles) or args.serial_only:  # (N > 1: every rank runs it on its tile share; rank 0 reports its own)
         pt.set_pipeline_depth(1)
         pt.set_batch_steps(1)
         pt.set_split_small_passes(False)
@@ -288,8 +288,8 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": "kPtTraceStream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "measured_in": "extra non-overlapped pass after the timed region: pipeline depth 1, 1 step per pass, %d steps, HIP events around every kernel on the launch stream"
-                           % k_serial,
+            "measured_in": "extra non-overlapped pass after the timed region: pipeline depth 1, 1 step per pass, %d steps, HIP events around every kernel on the launch stream%s"
+                           % (k_serial, "" if world == 1 else "; rank 0's tile share (1/%d of the frame)" % world),
             "algorithmic_bytes_per_launch": int(algo_bytes / launches), "avg_launch_ms": round(trace_ms / launches, 4), "launches": launches,
             "serial_pass_wall_ms": round(s_el * 1e3, 3), "sum_kernel_ms": round(ss["totalKernelMs"], 3),
             "bytes_per_ray": round(algo_bytes / max(ss["rays"], 1), 2),
