@@ -661,7 +661,10 @@ MVRT_DI f3 voxelEmission( const SvoDev& s, uint32_t vIndex, bool withScale ) // 
 // ---- shade + compact: stage k consumes the hits of trace k, adds the contributions that became known,
 // and for paths whose bounce ray hit, shades the hit (depth k of the reference loop, voxKernel.cu:691-760),
 // writing the survivor to its STABLE compacted slot of the other PathSet. --------------------------------
-__global__ void __launch_bounds__( CBLOCK ) kPtShade( PtParams P, int stage, int inSet )
+#ifndef MVRT_SHADE_WAVES
+#define MVRT_SHADE_WAVES 5 // waves per SIMD the shade kernel is register-budgeted for
+#endif
+__global__ void __launch_bounds__( CBLOCK, MVRT_SHADE_WAVES ) kPtShade( PtParams P, int stage, int inSet )
 {
 	__shared__ uint32_t waveCnt[CBLOCK / WAVE];
 	const uint64_t n = P.buf.liveCount[stage];

@@ -183,7 +183,7 @@ def test_bench_rccl_branch_runs_on_one_gpu():
     s.close()
     env = dict(os.environ, MVRT_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360", "--grid-res", "512",
-                                   "--detail", "0.25", "--no-cpu-baseline", "--no-serial-pass"], env=env, timeout=600).decode()
+                                   "--detail", "0.25", "--no-cpu-baseline"], env=env, timeout=600).decode()
     line = json.loads(out.strip().split("\n")[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["gather_ok"] is True
     assert "RCCL" in line["config"]["parallelism"]
