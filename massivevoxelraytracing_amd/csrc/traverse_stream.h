@@ -427,6 +427,9 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						if( base >= total )
 						{
 							exhausted = true;
+							// a wave that only drains its last rays is on the launch's critical path: let it win issue arbitration against the waves of
+							// a sibling pass that shares the SIMD (1/8 tile share: -1 % dragon, -3 % rtcamp; nothing on a full frame)
+							__builtin_amdgcn_s_setprio( 3 );
 							break;
 						}
 						chunkNext = (uint32_t)base;
