@@ -344,7 +344,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 {
 	constexpr bool EMBED = FL == 0, TREE = FL == 2;
 	constexpr uint32_t MVRT_RING = MVRT_RING_OF( FL );
-	constexpr uint32_t MVRT_RING_CLASH = MVRT_RING == 4 ? 0x11111111u : 0x01010101u; // the levels that share ring slot 0
+	constexpr uint32_t MVRT_RING_CLASH = MVRT_RING == 4 ? 0x11111111u : ( MVRT_RING == 8 ? 0x01010101u : 0x00010001u ); // the levels that share ring slot 0
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = (uint32_t)total64;
 	const Node64* __restrict__ nodes = s.nodes;
