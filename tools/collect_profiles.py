@@ -18,7 +18,8 @@ if os.path.exists(os.path.join(src, "pmc_summary.txt")):
         "# kPtTraceStream / kPtShade of 4 serial-mode steps; FETCH_SIZE / WRITE_SIZE in KB, gather-calibrated factor 1.0 -- profiles/r01_traffic_pmc.txt)\n" + txt)
 def counter(d, kernel, name):
     tot = 0.0
-    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # the newest run only (a re-used tag keeps the older pid-named files beside it)
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"] and r["Counter_Name"] == name:
                 tot += float(r["Counter_Value"])

@@ -17,7 +17,7 @@ def short(name):
 
 
 def main(src, dst):
-    stats = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)[0]
+    stats = sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]  # the newest run
     rows = {}
     with open(stats) as f:
         for r in csv.DictReader(f):

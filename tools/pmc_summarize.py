@@ -4,7 +4,7 @@ import csv, glob, os, re, sys, collections
 def short(n):
     return re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::", "", n))[:40]
 for d in sys.argv[1:]:
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:  # the newest run
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
