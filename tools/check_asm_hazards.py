@@ -18,20 +18,45 @@ for l in open(path):
         m = re.match(r"\s+s_nop (\d+)", l)
         if m:  # s_nop N = N + 1 wait states
             ins.extend(["s_nop (wait state)"] * int(m.group(1)))
+def sgprs(tok):
+    """the SGPR numbers an operand names: s5 -> {5}, s[4:5] -> {4, 5}, vcc -> {'vcc'}"""
+    tok = tok.strip()
+    if tok.startswith("vcc"):
+        return {"vcc"}
+    m = re.match(r"s\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"s(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def valu_sgpr_writes(p):
+    """SGPRs a VALU instruction writes: v_cmp* / v_cmpx* destinations (implicit vcc for _e32), the carry-out of v_add_co / v_sub_co / v_addc_co / ...,
+    v_div_scale's second destination, v_readlane / v_readfirstlane, v_mad_u64_u32's carry"""
+    op = p.split()[0]
+    ops = [t for t in p[len(op):].split(",")]
+    if op.startswith(("v_cmp", "v_cmpx")):
+        return {"vcc"} if op.endswith("_e32") else sgprs(ops[0])
+    if op.startswith(("v_readfirstlane", "v_readlane")):
+        return sgprs(ops[0])
+    if re.match(r"v_(add|sub|subrev|addc|subb|subbrev)_co", op) or op.startswith(("v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32")):
+        return sgprs(ops[1]) if len(ops) > 1 else set()
+    return set()
+
+
 bad = n = 0
 for k, l in enumerate(ins):
-    m = re.match(r"v_cndmask_b32 (\S+), (\S+), (\S+), (s\[(\d+):(\d+)\]|vcc)$", l)
+    m = re.match(r"v_cndmask_b32 (\S+), (\S+), (\S+), (s\[\d+:\d+\]|vcc)$", l)
     if not m:
         continue
     n += 1
-    mask = m.group(4)
-    lo = m.group(5)
+    mask = sgprs(m.group(4))
     for back in (1, 2):
         p = ins[k - back]
-        writes = p.startswith("v_cmp") and (mask in p.split(",")[0] or (mask == "vcc" and "_e32" in p.split()[0]))
-        writes |= p.startswith(("v_readfirstlane", "v_readlane")) and lo is not None and re.search(r"\bs%s\b" % lo, p.split(",")[0]) is not None
-        if writes:
+        if p.startswith("v_") and valu_sgpr_writes(p) & mask:  # any overlap with the mask pair
             bad += 1
             print("HAZARD?", p, " ->", l)
+# (the scan is linear: a select that is the target of a branch is checked against the instructions that precede it in the text, not against the
+# branch's source block -- every asm select of traverse_stream.h sits in straight-line code behind SALU-produced masks)
 print("asm v_cndmask selects: %d, suspicious producer within 2 instructions: %d" % (n, bad))
 sys.exit(1 if bad else 0)
