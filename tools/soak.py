@@ -15,13 +15,13 @@ res = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rgba, hw, hh = O.decode_rgbe(hdr_bytes())
 H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(os.environ.get("MVRT_SOAK_SEED", "2026")))
 W, Hh, iters = 176, 99, 2   # W*H not a multiple of 256
 bad = 0
 def scene_list():
     t = bunny_tris(); c, e = position_colors(t)
     yield "bunny", t.reshape(-1, 3), c.reshape(-1, 3), e.reshape(-1, 3)
-    for name, fn in (("dragon stand-in", scenes.dragon_standin), ("rtcamp stand-in", scenes.rtcamp_standin)):
+    for name, fn in (("dragon stand-in", scenes.dragon_standin), ("rtcamp stand-in", scenes.rtcamp_standin), ("cave stand-in", scenes.cave_standin)):
         v, c, e = fn(0.25)
         yield name, v, c, e
 for name, v, c, e in scene_list():
