@@ -924,8 +924,8 @@ static int allocWork( mvrt_pt* pt )
 	if( pt->drain() ) return 1;
 	if( !pt->statsBuf.p )
 	{
-		if( pt->statsBuf.alloc( 16 * 8 ) ) return 1;
-		MVRT_HIP( hipMemset( pt->statsBuf.p, 0, 16 * 8 ) );
+		if( pt->statsBuf.alloc( 64 * 8 ) ) return 1;
+		MVRT_HIP( hipMemset( pt->statsBuf.p, 0, 64 * 8 ) );
 	}
 	if( !pt->forkEv ) MVRT_HIP( hipEventCreateWithFlags( &pt->forkEv, hipEventDisableTiming ) );
 	// Footprint: every in-flight pass owns ~190 bytes of path state per sample (two ping-pong path sets, ray directions, hit records, per-sample
@@ -1325,7 +1325,7 @@ MVRT_EXPORT int mvrt_pt_reset_stats( mvrt_pt* pt )
 {
 	REQUIRE( pt, "null argument" );
 	if( pt->drain() ) return 1;
-	if( pt->buf.stats ) MVRT_HIP( hipMemset( pt->buf.stats, 0, 16 * 8 ) );
+	if( pt->buf.stats ) MVRT_HIP( hipMemset( pt->buf.stats, 0, 64 * 8 ) );
 	pt->prof.collect();
 	pt->prof.ms[0] = pt->prof.ms[1] = pt->prof.ms[2] = 0.0;
 	pt->prof.traceLaunches = 0;
@@ -1355,6 +1355,10 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 			// the lanes active in them
 			fprintf( stderr, "[util] wave-iterations %llu, active-lane-iterations %llu (%.1f%% of lane slots); refill events %llu; rays %llu -> %.2f lane-iterations per ray\n", u[2], u[3],
 					 100.0 * u[3] / ( 64.0 * ( u[2] ? u[2] : 1 ) ), u[0], (unsigned long long)s[0], (double)u[3] / (double)( s[0] ? s[0] : 1 ) );
+			unsigned long long w[48];
+			MVRT_HIP( hipMemcpy( w, pt->buf.stats + 16, sizeof( w ), hipMemcpyDeviceToHost ) );
+			for( int k = 0; k <= MVRT_MAX_DEPTH; k++ )
+				fprintf( stderr, "[util] stage %d: longest wave %llu iterations, waves %llu, longest ray %llu iterations\n", k, w[k], w[16 + k], w[32 + k] );
 		}
 	}
 	pt->prof.collect();

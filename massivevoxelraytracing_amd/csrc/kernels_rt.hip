@@ -36,6 +36,7 @@ struct BatchIO
 	uint32_t* descentsOut;
 #ifdef MVRT_UTIL_STATS
 	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+	uint32_t utilMaxRayIters = 0;
 #endif
 	MVRT_DI bool load( uint32_t i, f3* ro, f3* rd ) const
 	{
@@ -93,6 +94,7 @@ struct PrimaryIO
 	uint32_t* descentsOut;
 #ifdef MVRT_UTIL_STATS
 	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+	uint32_t utilMaxRayIters = 0;
 #endif
 	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
 	MVRT_DI bool load( uint32_t pixelIdx, f3* ro, f3* rd )
@@ -475,6 +477,7 @@ struct PtIO
 	int shadowKind;
 #ifdef MVRT_UTIL_STATS
 	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+	uint32_t utilMaxRayIters = 0;
 #endif
 	uint32_t dNormal, dShadow, nHits; // per-lane tallies (a lane sees far fewer than 2^32 descents per launch)
 	MVRT_DI int kindOf( uint32_t r, uint32_t* i ) const
@@ -561,6 +564,17 @@ __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kPtTraceStream( PtP
 		atomicAdd( &P.buf.stats[8 + 1], io.utilActive );
 		atomicAdd( &P.buf.stats[8 + 2], io.utilTailIters );
 		atomicAdd( &P.buf.stats[8 + 3], io.utilTailActive );
+		atomicMax( &P.buf.stats[16 + stage], io.utilTailIters ); // longest-lived wave of the stage's launches, in node-visit iterations
+		atomicAdd( &P.buf.stats[32 + stage], 1ull );			  // waves that worked
+	}
+	{
+		unsigned long long m = io.utilMaxRayIters;
+		for( int o = 32; o > 0; o >>= 1 )
+		{
+			const unsigned long long t = __shfl_xor( m, o );
+			m = t > m ? t : m;
+		}
+		if( threadIdx.x == 0 ) atomicMax( &P.buf.stats[48 + stage], m ); // longest ray of the stage, in node-visit iterations
 	}
 #endif
 	if( threadIdx.x == 0 )

@@ -395,6 +395,9 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		h->descents = descents;
 	};
 
+#ifdef MVRT_UTIL_STATS
+	uint32_t utilVis = 0; // node-visit iterations of the lane's current ray
+#endif
 	for( ;; )
 	{
 		// ---------------- (1) refill: control only gets here when enough lanes are idle ----------------
@@ -472,6 +475,10 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						tz1 = ( s.hiz - ro.z ) * iz;
 						descents = 0;
 						path = 0;
+#ifdef MVRT_UTIL_STATS
+						io.utilMaxRayIters = utilVis > io.utilMaxRayIters ? utilVis : io.utilMaxRayIters;
+						utilVis = 0;
+#endif
 						vMaskHi = vMask | 24u;
 						if( min3f( tx1, ty1, tz1 ) < max3f( t0x, t0y, t0z ) ) // :275-278 misses the root box
 						{
@@ -516,6 +523,9 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					finishedHit( &h );
 					io.store( ray, h, isShadow );
 				}
+#ifdef MVRT_UTIL_STATS
+				io.utilMaxRayIters = utilVis > io.utilMaxRayIters ? utilVis : io.utilMaxRayIters;
+#endif
 				break; // every lane idle and the stream is empty: the wave retires
 			}
 		}
@@ -682,6 +692,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		{
 			const lmask act = actM;
 #ifdef MVRT_UTIL_STATS
+			utilVis += LANE( act ) ? 1u : 0u;
 			if( lane == 0 ) // per wave-ITERATION tallies (the block above counts refill events)
 			{
 				io.utilTailIters++;
