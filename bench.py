@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 RANDOM_LINE_CEILING_GBS = 3200.0  # measured on the box: 50 G random 64-byte lines per second (tools/calib/gather_rate.hip)
+STREAM_READ_CEILING_GBS = 6100.0  # measured on the box: tools/calib/stream_read.hip, 8-32 GiB buffers (profiles/r02_stream_read.txt); SURVEY.md 8d's second denominator
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured copy)
 
 
@@ -82,6 +83,7 @@ def stress(args, mv):
                    "resident_structure_gb": round(svo.traversal_bytes() / 1e9, 2),
                    "embedded_mask": int(info.embeddedMask), "svo_build_s": round(build_s, 2), "hits": hits, "descents_per_ray": round(float(desc.mean()), 2)},
         "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<2> (tree flavour: two-level bricks)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "measured_stream_read_gbs": STREAM_READ_CEILING_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
                      "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "random_line_ceiling_gbs": RANDOM_LINE_CEILING_GBS,
                      "line_frac_of_ceiling": round(line_bytes * args.steps / el / 1e9 / RANDOM_LINE_CEILING_GBS, 3),
@@ -288,6 +290,7 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": "kPtTraceStream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "measured_stream_read_gbs": STREAM_READ_CEILING_GBS, "frac_of_measured_stream_read": round(achieved / STREAM_READ_CEILING_GBS, 5),
             "measured_in": "extra non-overlapped pass after the timed region: pipeline depth 1, 1 step per pass, %d steps, HIP events around every kernel on the launch stream%s"
                            % (k_serial, "" if world == 1 else "; rank 0's tile share (1/%d of the frame)" % world),
             "algorithmic_bytes_per_launch": int(algo_bytes / launches), "avg_launch_ms": round(trace_ms / launches, 4), "launches": launches,
