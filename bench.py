@@ -84,13 +84,22 @@ def stress(args, mv):
                    "embedded_mask": int(info.embeddedMask), "svo_build_s": round(build_s, 2), "hits": hits, "descents_per_ray": round(float(desc.mean()), 2)},
         "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<2> (tree flavour: two-level bricks)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "measured_stream_read_gbs": STREAM_READ_CEILING_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
+                     "traffic": stress_traffic(n_rays), "traffic_source": "profiles/traffic_stress.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/stress_traffic.sh)",
+                     "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
                      "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "random_line_ceiling_gbs": RANDOM_LINE_CEILING_GBS,
                      "line_frac_of_ceiling": round(line_bytes * args.steps / el / 1e9 / RANDOM_LINE_CEILING_GBS, 3),
                      "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts one new 64-byte brick line per two descents; "
                              "random_line_ceiling_gbs = what the chip serves for divergent 64-byte-line gathers at 128 GiB footprint "
                              "(tools/calib/gather_rate.hip, profiles/r01_gfx950_issue_and_gather_costs.txt)"},
     }), flush=True)
+
+
+def stress_traffic(n_rays):
+    """fabric-side bytes per launch of the config-5 traversal kernel, from the committed PMC passes (HBM-side bytes cannot be read live)"""
+    p = os.path.join(ROOT, "profiles", "traffic_stress.json")
+    if not os.path.exists(p):
+        return None
+    return int(json.load(open(p))["traffic_bytes_per_ray"] * n_rays)
 
 
 def main():

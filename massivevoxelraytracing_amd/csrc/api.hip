@@ -188,7 +188,7 @@ struct mvrt_svo
 		}
 		const uint64_t lanes = traceWorkspaceLanes();
 		const uint64_t rows = 2 * (uint64_t)( info.levels ? info.levels : 1 ) + 2; // fast path: 1 row per level; irregular rays: 2 per slot
-		const uint64_t bytes = 256 + rows * lanes * ( sizeof( uint4 ) + sizeof( uint32_t ) );
+		const uint64_t bytes = 256 + rows * lanes * ( sizeof( uint4 ) + 2 * sizeof( uint32_t ) );
 		if( wsBuf.bytes < bytes )
 		{
 			if( wsBuf.alloc( bytes ) ) return 1;
@@ -197,6 +197,7 @@ struct mvrt_svo
 		ws.spill = (uint4*)( (uint8_t*)wsBuf.p + 256 );
 		ws.spillStride = lanes;
 		ws.spillMask = (uint32_t*)( ws.spill + rows * lanes );
+		ws.spillMask2 = ws.spillMask + rows * lanes;
 		return 0;
 	}
 	SvoDev dev() const
@@ -968,7 +969,7 @@ static int ensureSlotWorkspace( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
 	const uint64_t lanes = traceWorkspaceLanes();
 	const uint64_t rows = 2 * (uint64_t)( pt->intersector->info.levels ? pt->intersector->info.levels : 1 ) + 2;
-	const uint64_t bytes = 256 + rows * lanes * ( sizeof( uint4 ) + sizeof( uint32_t ) );
+	const uint64_t bytes = 256 + rows * lanes * ( sizeof( uint4 ) + 2 * sizeof( uint32_t ) );
 	if( sl.wsBuf.bytes < bytes )
 	{
 		if( sl.wsBuf.alloc( bytes ) ) return 1;
@@ -977,6 +978,7 @@ static int ensureSlotWorkspace( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	sl.ws.spill = (uint4*)( (uint8_t*)sl.wsBuf.p + 256 );
 	sl.ws.spillStride = lanes;
 	sl.ws.spillMask = (uint32_t*)( sl.ws.spill + rows * lanes );
+	sl.ws.spillMask2 = sl.ws.spillMask + rows * lanes;
 	return 0;
 }
 

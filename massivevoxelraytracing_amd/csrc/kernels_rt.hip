@@ -73,13 +73,14 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 #define MVRT_TRACE_WAVES 7 // waves per SIMD the traversal kernels are register-budgeted for (72 VGPRs)
 #endif
 // the embedded flavour's 8 KiB LDS ring admits 5 waves per SIMD (5, 6 and 7 perform alike on cache-resident octrees, profiles/r02_traversal_experiments.txt)
-#define MVRT_WAVES_OF( FL ) ( ( FL ) == 0 && MVRT_RING_EMBED >= 8 && MVRT_TRACE_WAVES > 40 / MVRT_RING_EMBED ? 40 / MVRT_RING_EMBED : MVRT_TRACE_WAVES )
+// ... and the tree flavour's 6 KiB per wave (4 KiB ring + two mask words per slot) 6
+#define MVRT_WAVES_OF( FL ) ( ( FL ) == 0 && MVRT_RING_EMBED >= 8 && MVRT_TRACE_WAVES > 40 / MVRT_RING_EMBED ? 40 / MVRT_RING_EMBED : ( ( FL ) == 2 && MVRT_TRACE_WAVES > 6 ? 6 : MVRT_TRACE_WAVES ) )
 template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
-	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
-	traceStream<FL>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask, ws.spillMask );
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : ( FL == 2 ? 2 : 1 ) * MVRT_RING_OF( FL ) * 64]; // (tree flavour: two mask words per stacked node)
+	traceStream<FL>( makeTraceCore( svo ), io, n, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask, ws.spillMask, ws.spillMask2 );
 }
 
 struct PrimaryIO
@@ -128,9 +129,9 @@ template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kRenderPrimaryStream( PrimaryIO io, TraceWorkspace ws, uint32_t chunk )
 {
 	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
-	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : ( FL == 2 ? 2 : 1 ) * MVRT_RING_OF( FL ) * 64]; // (tree flavour: two mask words per stacked node)
 	traceStream<FL>( makeTraceCore( io.svo ), io, (uint64_t)io.W * io.H, ws.cursor, chunk, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
-						ws.spillMask );
+						ws.spillMask, ws.spillMask2 );
 }
 
 static uint32_t streamChunk( uint64_t total, uint64_t waves )
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kPtTraceStream( PtP
 																			uint32_t raysPerLane, uint32_t minWaves )
 {
 	__shared__ uint4 ring[MVRT_RING_OF( FL ) * 64];
-	__shared__ uint32_t ringMask[FL == 0 ? 1 : MVRT_RING_OF( FL ) * 64];
+	__shared__ uint32_t ringMask[FL == 0 ? 1 : ( FL == 2 ? 2 : 1 ) * MVRT_RING_OF( FL ) * 64]; // (tree flavour: two mask words per stacked node)
 	PtIO io;
 	io.table = P.buf.selfDev;
 	io.setIdx = setIdx;
@@ -555,7 +556,7 @@ __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kPtTraceStream( PtP
 	if( c < 64 ) c = 64;
 	if( c > chunk ) c = chunk;
 	traceStream<FL>( makeTraceCore( P.svo ), io, total, P.buf.cursors + stage, (uint32_t)c, ring, ws.spill, ws.spillStride, (uint64_t)blockIdx.x * 64 + threadIdx.x, ringMask,
-						ws.spillMask );
+						ws.spillMask, ws.spillMask2 );
 	unsigned long long dN = waveSum( (unsigned long long)io.dNormal ), dS = waveSum( (unsigned long long)io.dShadow ), nH = waveSum( (unsigned long long)io.nHits );
 #ifdef MVRT_UTIL_STATS
 	if( threadIdx.x == 0 )

@@ -56,6 +56,7 @@ struct TraceWorkspace
 	uint64_t* paths; // per-ray voxel paths of batch / primary-cast launches, resolved to vIndex by a dense pass
 	uint64_t pathCap;
 	uint32_t* spillMask; // non-embedded flavour: node masks of evicted stack entries, [level][lane]
+	uint32_t* spillMask2; // tree flavour: the second mask word of evicted entries
 };
 uint64_t traceWorkspaceLanes();
 

@@ -724,7 +724,11 @@ __global__ void __launch_bounds__( BB ) kMakeBricks( const uint8_t* __restrict__
 		}
 		nd.psum[0] = lo;
 		nd.psum[1] = hi;
-		nd.psum[2] = mask; // the brick root's own mask: what a descent INTO this brick fetches
+		nd.psum[2] = mask; // the brick root's own mask
+		// where the children of the first existing child start.  The children of consecutive nodes lie back to back (every level is numbered in Morton
+		// order), so child c's start is this + popcount( child masks before c ): psum[0..3] are the 16 bytes a descent INTO this brick fetches, and all
+		// the traversal needs of the line (traverse_stream.h, treeDescend)
+		nd.psum[3] = mask ? nd.children[__builtin_ctz( mask )] : 0u;
 		bricksOfLevel[g] = nd;
 	}
 }
