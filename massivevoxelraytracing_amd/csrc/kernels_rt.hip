@@ -73,8 +73,11 @@ __global__ void __launch_bounds__( 256 ) kResolveVIndex( SvoDev svo, uint64_t n,
 #define MVRT_TRACE_WAVES 7 // waves per SIMD the traversal kernels are register-budgeted for (72 VGPRs)
 #endif
 // the embedded flavour's 8 KiB LDS ring admits 5 waves per SIMD (5, 6 and 7 perform alike on cache-resident octrees, profiles/r02_traversal_experiments.txt)
-// ... and the tree flavour's 6 KiB per wave (4 KiB ring + two mask words per slot) 6
-#define MVRT_WAVES_OF( FL ) ( ( FL ) == 0 && MVRT_RING_EMBED >= 8 && MVRT_TRACE_WAVES > 40 / MVRT_RING_EMBED ? 40 / MVRT_RING_EMBED : ( ( FL ) == 2 && MVRT_TRACE_WAVES > 6 ? 6 : MVRT_TRACE_WAVES ) )
+#ifndef MVRT_TREE_WAVES
+#define MVRT_TREE_WAVES ( MVRT_RING_TREE >= 8 ? 3 : 6 )
+#endif
+// ... and the tree flavour's 12 KiB per wave (8-slot ring + two mask words per slot) 3
+#define MVRT_WAVES_OF( FL ) ( ( FL ) == 0 && MVRT_RING_EMBED >= 8 && MVRT_TRACE_WAVES > 40 / MVRT_RING_EMBED ? 40 / MVRT_RING_EMBED : ( ( FL ) == 2 && MVRT_TRACE_WAVES > MVRT_TREE_WAVES ? MVRT_TREE_WAVES : MVRT_TRACE_WAVES ) )
 template <int FL>
 __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kTraceBatchStream( SvoDev svo, uint64_t n, BatchIO io, TraceWorkspace ws, uint32_t chunk )
 {

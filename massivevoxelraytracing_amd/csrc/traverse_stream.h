@@ -41,7 +41,8 @@
 //        the CONSUMER of the hit sums nVoxelsPSum along it (voxelIndexFromPath) in a dense kernel where
 //        all 64 lanes walk together.  This also removes the nVoxelsPSum load from every descent.
 //    An entry is {child reference (index | mask << 24), tx1, ty1, tz1} = one ds_write_b128.
-//  * LDS ring per lane (slot = level & (slots - 1); 8 slots = 8 KiB per wave for the embedded flavour, 4 for the others, see MVRT_RING_OF).
+//  * LDS ring per lane (slot = level & (slots - 1); 8 slots = 8 KiB per wave for the embedded flavour, 8 + mask words = 12 KiB for the tree flavour, 4 for plain
+//    indices, see MVRT_RING_OF).
 //    A push that lands on an occupied slot first evicts that (shallower) entry to an HBM spill array
 //    laid out [level][lane] (coalesced 1 KiB rows); a pop of an evicted level reads it back.  Hot
 //    pushes and pops near the leaves never leave LDS.
@@ -58,7 +59,11 @@
 #ifndef MVRT_RING_EMBED
 #define MVRT_RING_EMBED 8
 #endif
-#define MVRT_RING_OF( FL ) ( ( FL ) == 0 ? MVRT_RING_EMBED : 4 )
+#ifndef MVRT_RING_TREE
+#define MVRT_RING_TREE 8 // tree flavour (13 levels at 8192^3): 8 slots = 12 KiB per wave with the two mask words, 3 waves per SIMD; measured on config 5: 4 slots (any of 3-6
+						 // waves per SIMD) 600 Mrays/s, 8 slots 630, 16 slots (1 wave per SIMD) 404 -- the evictions cost, the occupancy does not
+#endif
+#define MVRT_RING_OF( FL ) ( ( FL ) == 0 ? MVRT_RING_EMBED : ( ( FL ) == 2 ? MVRT_RING_TREE : 4 ) )
 #ifndef MVRT_REFILL_MIN
 #define MVRT_REFILL_MIN 20 // refill once this many lanes are idle (or all of them)
 #endif
