@@ -105,6 +105,7 @@ def stress_traffic(n_rays):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--build-flags", type=int, default=0, help="octree build flags (MVRT_BUILD_*); 0 = the reference's DAG with embedded masks")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid-res", type=int, default=0, help="0 = the scene's BASELINE size (dragon 2048, rtcamp 4096, cave 2048)")
@@ -169,7 +170,10 @@ def main():
     hdr = os.path.join(ROOT, "tests", "golden", "monks_forest_s.hdr")
     pt.loadHDRI(None, hdr, hdr)
     t_build = time.time()
-    pt.updateScene(verts, cols, emis, None, origin, dps, args.grid_res)
+    if args.build_flags:  # experiment knob: the other octree flavours on the same scene (1 no DAG, 2 plain indices, 3 two-level bricks, 4 conservative voxelization)
+        pt.m_intersectorOctreeGPU.build(verts, cols, emis, None, origin, dps, args.grid_res, flags=args.build_flags)
+    else:
+        pt.updateScene(verts, cols, emis, None, origin, dps, args.grid_res)
     mv.synchronize()
     build_s = time.time() - t_build
     info = pt.m_intersectorOctreeGPU.info()
