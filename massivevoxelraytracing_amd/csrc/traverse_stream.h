@@ -89,14 +89,23 @@ MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 		v = e.y;
 		l0 = s.topLevels;
 	}
+	uint32_t ref = 0; // embedded flavour: the reference the walk arrived through (index | the node's own mask << 24), once one was read
 	for( uint32_t l = l0; l < s.levels; l++ )
 	{
 		const uint32_t c = (uint32_t)( path >> ( 3u * ( s.levels - 1u - l ) ) ) & 7u;
 		const Node64* nd = s.nodes + n;
 		if( s.embedded )
 		{
+			if( l + 1u == s.levels && l > l0 )
+			{
+				// the parent of the voxel: its children are voxels, one each, so its nVoxelsPSum[c] is the number of its children before c --
+				// a popcount of the mask that came with the reference to it: no fetch for the last level
+				v += (uint32_t)__popc( ( ref >> 24 ) & ( ( 1u << c ) - 1u ) );
+				break;
+			}
 			v += nd->psum[c];
-			n = nd->children[c] & 0xFFFFFFu;
+			ref = nd->children[c];
+			n = ref & 0xFFFFFFu;
 		}
 		else
 		{
