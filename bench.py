@@ -70,9 +70,14 @@ def stress(args, mv):
     desc = de.to_host().astype(np.uint64)
     hits = int((t.to_host() != mv.MAX_FLOAT).sum())
     algo = n_rays * 40 + int(desc.sum()) * 8 + hits * 8
-    # what the dependent pointer chase really moves: one NEW 64-byte line per two descents (two-level bricks; the in-between descent re-reads the
-    # line the previous one fetched)
-    line_bytes = int(desc.sum()) * 32
+    # what the dependent pointer chase really moves: one brick (16 bytes of a 64-byte line) per two descents; sibling bricks share lines, so the
+    # lines actually fetched are fewer -- taken from the committed counter passes (fabric read requests per ray) when they are there
+    bricks = int(desc.sum()) // 2
+    reqs = None
+    tp = os.path.join(ROOT, "profiles", "traffic_stress.json")
+    if os.path.exists(tp):
+        reqs = json.load(open(tp)).get("read_requests_per_ray")
+    line_bytes = int((reqs * n_rays if reqs else bricks) * 64)
     gbs = algo * args.steps / el / 1e9
     print(json.dumps({
         "metric": "Mrays/sec (incoherent rays, HBM-resident synthetic octree)", "value": round(n_rays * args.steps / el / 1e6, 2), "unit": "Mrays/s", "n_gpus": 1,
@@ -88,7 +93,9 @@ def stress(args, mv):
                      "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
                      "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "random_line_ceiling_gbs": RANDOM_LINE_CEILING_GBS,
                      "line_frac_of_ceiling": round(line_bytes * args.steps / el / 1e9 / RANDOM_LINE_CEILING_GBS, 3),
-                     "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts one new 64-byte brick line per two descents; "
+                     "bricks_entered_per_launch": bricks,
+                     "note": "achieved counts 4-8 useful bytes per descent; line_gbs counts the 64-byte fabric reads of the committed counter passes "
+                             "(profiles/traffic_stress.json; one per brick entered -- two descents -- without them); "
                              "random_line_ceiling_gbs = what the chip serves for divergent 64-byte-line gathers at 128 GiB footprint "
                              "(tools/calib/gather_rate.hip, profiles/r01_gfx950_issue_and_gather_costs.txt)"},
     }), flush=True)

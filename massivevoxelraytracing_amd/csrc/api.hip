@@ -381,7 +381,7 @@ MVRT_EXPORT uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo )
 {
 	if( !svo || !svo->nodes ) return 0;
 	const uint64_t n = svo->info.numberOfNodes;
-	if( svo->tree ) return (uint64_t)svo->nBricks * sizeof( Node64 ) + n * 5;
+	if( svo->tree ) return (uint64_t)svo->nBricks * sizeof( uint4 ) + n * 5;
 	return n * sizeof( Node64 ) + n + ( svo->psumCold ? n * 32 : 0 ) + svo->topTable.bytes + svo->kids.bytes;
 }
 MVRT_EXPORT const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->nodes : nullptr; }

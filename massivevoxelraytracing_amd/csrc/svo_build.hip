@@ -700,36 +700,32 @@ __global__ void __launch_bounds__( BB ) kMakeNodesTree( const Task* __restrict__
 // translate the children's first-child indices (nodes two levels below) into brick indices; childIsBottom: the children are parents of voxels
 // and their cFirst already IS a voxel index.
 __global__ void __launch_bounds__( BB ) kMakeBricks( const uint8_t* __restrict__ cMask, const uint32_t* __restrict__ cFirst, uint32_t levelBase, uint32_t count, int childIsBottom,
-													  uint32_t grandBase, uint32_t grandBrickBase, Node64* __restrict__ bricksOfLevel )
+													  uint32_t grandBase, uint32_t grandBrickBase, uint4* __restrict__ bricksOfLevel )
 {
 	for( uint64_t g = (uint64_t)blockIdx.x * BB + threadIdx.x; g < count; g += (uint64_t)gridDim.x * BB )
 	{
 		const uint32_t r = levelBase + (uint32_t)g;
 		const uint32_t mask = cMask[r];
 		uint32_t k = cFirst[r];
-		Node64 nd;
-		uint32_t lo = 0, hi = 0;
+		uint32_t lo = 0, hi = 0, base = 0;
+		bool first = true;
 		for( int c = 0; c < 8; c++ )
 		{
-			nd.children[c] = MVRT_LEAF;
-			nd.psum[c] = 0;
 			if( mask >> c & 1u )
 			{
 				const uint32_t m = cMask[k];
-				nd.children[c] = childIsBottom ? cFirst[k] : grandBrickBase + ( cFirst[k] - grandBase );
+				if( first ) base = childIsBottom ? cFirst[k] : grandBrickBase + ( cFirst[k] - grandBase );
+				first = false;
 				if( c < 4 ) lo |= m << ( 8 * c );
 				else hi |= m << ( 8 * ( c - 4 ) );
 				k++;
 			}
 		}
-		nd.psum[0] = lo;
-		nd.psum[1] = hi;
-		nd.psum[2] = mask; // the brick root's own mask
-		// where the children of the first existing child start.  The children of consecutive nodes lie back to back (every level is numbered in Morton
-		// order), so child c's start is this + popcount( child masks before c ): psum[0..3] are the 16 bytes a descent INTO this brick fetches, and all
-		// the traversal needs of the line (traverse_stream.h, treeDescend)
-		nd.psum[3] = mask ? nd.children[__builtin_ctz( mask )] : 0u;
-		bricksOfLevel[g] = nd;
+		// A brick is 16 bytes: the masks of the root's eight children (byte c = child c, 0 = absent), the root's own mask, and where the children
+		// of its first existing child start (bricks two levels down, or voxels).  The children of consecutive nodes lie back to back -- every level
+		// is numbered in Morton order -- so child c's start is base + popcount( child masks before c ): nothing else of the brick is ever read
+		// (traverse_stream.h, treeDescend), and the up to eight bricks below one node share 128 bytes.
+		bricksOfLevel[g] = make_uint4( lo, hi, mask, base );
 	}
 }
 // distinct parents per level for ALL levels in one pass (the reference's octreeTaskInit counters, voxKernel.cu:257-265)
@@ -966,7 +962,7 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 						if( l & 1 ) nBr += hc[l];
 					}
 					nBricks = (uint32_t)nBr;
-					if( treeFirst.alloc( total * 4 ) || bricks.alloc( ( nBr ? nBr : 1 ) * sizeof( Node64 ) ) ) return 1;
+					if( treeFirst.alloc( total * 4 ) || bricks.alloc( ( nBr ? nBr : 1 ) * sizeof( uint4 ) ) ) return 1;
 					levelNodes.push_back( nullptr );
 				}
 				else
@@ -982,7 +978,7 @@ static int buildFromFragments( Buf& keysA, Buf& valsA, unsigned long long totalD
 									treeFirst.as<uint32_t>(), nxt );
 				if( level & 1 )
 					hipLaunchKernelGGL( kMakeBricks, dim3( gridFor( nGroups ) ), dim3( BB ), 0, st, levelMasks[0], treeFirst.as<uint32_t>(), treeLevelBase[level], nGroups, level - 1 == 0 ? 1 : 0,
-										level >= 2 ? treeLevelBase[level - 2] : 0u, level >= 2 ? treeBrickBase[level - 2] : 0u, bricks.as<Node64>() + treeBrickBase[level] );
+										level >= 2 ? treeLevelBase[level - 2] : 0u, level >= 2 ? treeBrickBase[level - 2] : 0u, bricks.as<uint4>() + treeBrickBase[level] );
 			}
 			else
 				hipLaunchKernelGGL( kMakeNodesDirect, dim3( gridFor( nInput ) ), dim3( BB ), 0, st, cur, (uint64_t)nInput, blockCnt.as<uint32_t>(), nodeBase, levelNodes[0], levelMasks[0], nxt );

@@ -224,7 +224,7 @@ MVRT_DI uint32_t nonZeroBytes( uint32_t lo, uint32_t hi ) // bit c = byte c of {
 }
 MVRT_DI void treeEnterBrick( const Node64* __restrict__ bricks, uint32_t at, uint32_t* node, uint32_t* nodeMask, uint32_t* bLo, uint32_t* bHi )
 {
-	const uint4 q = *(const uint4*)&bricks[at].psum[0]; // THE dependent line fetch of two levels
+	const uint4 q = ( (const uint4*)bricks )[at]; // THE dependent fetch of two levels: a 16-byte brick (`nodes` of a tree-flavour octree are bricks, not Node64 lines)
 	*bLo = q.x;
 	*bHi = q.y;
 	*nodeMask = q.z;
