@@ -110,7 +110,8 @@ int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale ); /* m_emissionScal
 uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo );
 /* m_nodeBuffer / m_vAttributeBuffer (:265-266): the device arrays.  Attributes are the reference's VoxelAttirb[numberOfVoxels]; nodes are
  * this library's 64-byte lines {u32 children[8]; u32 nVoxelsPSum[8]} (the reference's 68-byte node minus its leading mask word, which rides
- * in bits 24-31 of the parent's pointer) -- use mvrt_svo_download for the reference layout. */
+ * in bits 24-31 of the parent's pointer); for an octree too large for that (no node sharing, > 2^24 nodes: the tree flavour) they are its 16-byte
+ * two-level bricks {u8 childMask[8]; u32 ownMask; u32 base} -- use mvrt_svo_download for the reference layout. */
 const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo );
 const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo );
 /* read the SVO back in the reference layout (parity checks of build); either pointer may be NULL */
