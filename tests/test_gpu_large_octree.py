@@ -106,13 +106,14 @@ def test_path_tracer_on_non_embedded_octree(mv, O):
     assert pt.stats()["rays"] == rays
 
 
-def test_path_tracer_on_tree_flavour(mv, O):
+@pytest.mark.parametrize("res", [128, 1024])  # 1024: 10 levels, deeper than the flavour's 8-slot ring (stack entries go through the spill rows)
+def test_path_tracer_on_tree_flavour(mv, O, res):
     """the GPU builder's "tree" flavour (no DAG, masks not embedded: {mask, first child} nodes + two-level bricks, hits report the voxel index
     directly -- no nVoxelsPSum walk) under the whole wavefront path tracer: frame buffer, ray and descent counters against the oracle on the
     reference-layout octree the library hands back (mvrt_svo_download), which in turn equals the oracle's own non-DAG build"""
     tris = bunny_tris()
     cols, emis = position_colors(tris)
-    res, w, h = 128, 150, 85
+    w, h = 150, 85
     sc = O.build_scene_from_triangles(tris, res, cols, emis, dag=False, embed=False)
     rgba, hw, hh = O.decode_rgbe(hdr_bytes())
     cam = probe_camera(sc.origin, sc.dps, res, focus=9.0, lens_r=0.05)
@@ -126,7 +127,7 @@ def test_path_tracer_on_tree_flavour(mv, O):
     got = nodes.view(O.NODE_DTYPE)
     for f in ("mask", "children", "psum"):
         assert np.array_equal(got[f], sc.nodes[f]), f
-    assert svo.traversal_bytes() < len(sc.nodes) * 40  # 5 B per node + a 64-byte brick for every second level
+    assert svo.traversal_bytes() < len(sc.nodes) * 16  # 5 B per node + a 16-byte brick for every second level
     for _ in range(2):
         pt.step(None, cam)
     H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
@@ -142,7 +143,9 @@ def test_path_tracer_on_tree_flavour(mv, O):
         assert st[k] == tot[k], k
 
 
-@pytest.mark.parametrize("res,n,flags", [(64, 5000, 3), (256, 200_000, 1), (512, 1_000_000, 3), (128, 300_000, 0)])
+# (the 2048^3 and 8192^3 cases: 11- and 13-level walks of the tree flavour -- deeper than its 8-slot LDS ring, so stack entries with their two mask words
+# go through the HBM spill rows -- against the oracle)
+@pytest.mark.parametrize("res,n,flags", [(64, 5000, 3), (256, 200_000, 1), (512, 1_000_000, 3), (128, 300_000, 0), (2048, 600_000, 3), (8192, 400_000, 3)])
 def test_synthetic_octree_matches_documented_generator(mv, O, res, n, flags):
     svo = mv.IntersectorOctreeGPU()
     svo.build_synthetic(res, n, seed=1234, flags=flags)
