@@ -291,6 +291,7 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 								 float dps, int gridRes, int hasEmission, int embeddedMask, void* stream )
 {
 	REQUIRE( svo && nodes68Host && numberOfNodes > 0, "mvrt_svo_upload: empty octree" );
+	REQUIRE( attribs8Host || numberOfVoxels == 0, "mvrt_svo_upload: %u voxels without attributes", numberOfVoxels );
 	REQUIRE( ilog2Exact( gridRes ) > 0, "gridRes %d is not a power of two >= 2 (IntersectorOctreeGPU.hpp:48-51)", gridRes );
 	REQUIRE( !embeddedMask || numberOfNodes < 0xFFFFFFu, "embedded masks need fewer than 0xFFFFFF nodes (IntersectorOctreeGPU.hpp:231), got %u", numberOfNodes );
 	hipStream_t st = (hipStream_t)stream;

@@ -601,7 +601,11 @@ MVRT_DI f3 hdriSampleNearest( const HdriDev& h, f3 d, bool isPrimary )
 	int x = (int)smin( smax( u * w, 0.0f ), (float)( w - 1.0f ) );
 	int y = (int)smin( smax( v * hh, 0.0f ), (float)( hh - 1.0f ) );
 	uint64_t index = (uint64_t)y * w + x;
-	float4 c = ( isPrimary && h.pixelsPrimary ) ? h.pixelsPrimary[index] : h.pixels[index];
+	const float4* px = ( isPrimary && h.pixelsPrimary ) ? h.pixelsPrimary : h.pixels;
+	// no map loaded: only possible with the lighting switched off (scale 0: mvrt_pt_step refuses scale > 0 without a map), where a loaded map would
+	// contribute pixel * 0 -- the reference reads m_pixels unconditionally here (voxKernel.cu:682) and its applications always load one
+	if( !px ) return mk3( 0.0f, 0.0f, 0.0f );
+	float4 c = px[index];
 	return mk3( c.x, c.y, c.z ) * h.scale;
 }
 MVRT_DI uint32_t satH( const HdriDev& h, const uint32_t* s, uint32_t x ) { return x == 0 ? 0u : s[h.width * ( h.height - 1 ) + x - 1]; }

@@ -1,0 +1,100 @@
+"""Error behaviour of the boundary on the GPU box (SURVEY.md 8b "Errors": the reference aborts or asserts -- hipUtil.hpp:141-179,
+IntersectorOctreeGPU.hpp:48-51,231; the C functions return a status and keep a message, the handle stays usable)."""
+import numpy as np
+import pytest
+
+from common import bunny_tris, hdr_bytes, position_colors, probe_camera
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def mv():
+    import massivevoxelraytracing_amd as m
+    m.lib()
+    return m
+
+
+def test_calls_out_of_order_report_and_recover(mv, O):
+    pt = mv.PathTracer()
+    cam = probe_camera(np.zeros(3, np.float32), np.float32(1.0 / 64), 64)
+    with pytest.raises(mv.MvrtError, match="mvrt_pt_setup first"):
+        pt.step(None, cam)
+    pt.setup(None)
+    with pytest.raises(mv.MvrtError, match="no scene"):
+        pt.step(None, cam)
+    svo = pt.m_intersectorOctreeGPU
+    ro = np.zeros((4, 3), np.float32)
+    rd = np.ones((4, 3), np.float32)
+    with pytest.raises(mv.MvrtError, match="no octree"):
+        svo.intersect(ro, rd)
+    with pytest.raises(mv.MvrtError, match="power of two"):
+        svo.build_synthetic(100, 10, seed=1)
+    with pytest.raises(mv.MvrtError, match="bad resolution"):
+        pt.resizeFrameBufferIfNeeded(None, 0, 16)
+    with pytest.raises(mv.MvrtError, match="bad tile"):
+        pt.set_tile(3, 3)
+    with pytest.raises(mv.MvrtError, match="pipeline depth"):
+        pt.set_pipeline_depth(9)
+    # ... and the same handles work afterwards, bit for bit
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    res, w, h = 64, 96, 54
+    sc = O.build_scene_from_triangles(tris, res, cols, emis)
+    pt.updateScene(tris.reshape(-1, 3), cols.reshape(-1, 3), emis.reshape(-1, 3), None, sc.origin, sc.dps, res)
+    with pytest.raises(mv.MvrtError, match="no frame buffer"):
+        pt.step(None, cam)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    with pytest.raises(mv.MvrtError, match="HDRI enabled"):  # the reference's default scale is 1.75: lighting is on until a map is loaded or the scale is set to 0
+        pt.step(None, cam)
+    rgba, hw, hh = O.decode_rgbe(hdr_bytes())
+    pt.loadHDRIPixels(None, rgba, hw, hh, rgba, hw, hh)
+    cam = probe_camera(sc.origin, sc.dps, res, focus=9.0, lens_r=0.05)
+    pt.step(None, cam)
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    fb, _, cnt = sc.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
+    assert np.array_equal(pt.read_framebuffer()[: w * h], fb) and pt.stats()["rays"] == cnt["rays"]
+
+
+def test_lighting_switched_off_without_a_map_renders_black_sky(mv, O):
+    """scale 0 and no HDRI loaded (the reference would read a null image for every primary miss, voxKernel.cu:682): equals a loaded map at scale 0"""
+    tris = bunny_tris()
+    cols, emis = position_colors(tris)
+    res, w, h = 64, 96, 54
+    sc = O.build_scene_from_triangles(tris, res, cols, emis)
+    cam = probe_camera(sc.origin, sc.dps, res, focus=9.0, lens_r=0.05)
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    pt.updateScene(tris.reshape(-1, 3), cols.reshape(-1, 3), emis.reshape(-1, 3), None, sc.origin, sc.dps, res)
+    pt.set_hdri_scale(0.0)
+    pt.step(None, cam)
+    rgba, hw, hh = O.decode_rgbe(hdr_bytes())
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    H.set_scale(0.0)
+    fb, _, cnt = sc.render_pt(H, cam, w, h, 0, math_mode=1, threads=8)
+    got = pt.read_framebuffer()[: w * h]
+    assert np.array_equal(got, fb) and pt.stats()["rays"] == cnt["rays"] and np.isfinite(got).all()
+
+
+def test_a_frame_that_cannot_fit_names_the_way_out(mv):
+    """a frame whose wavefront state exceeds the free HBM is refused before anything is allocated, and the message names the remedy"""
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.m_intersectorOctreeGPU.build_synthetic(64, 5000, seed=3)
+    pt.set_hdri_scale(0.0)
+    pt.set_batch_steps(1)
+    cam = probe_camera(np.zeros(3, np.float32), np.float32(1.0 / 64), 64)
+    with pytest.raises(mv.MvrtError, match="mvrt_pt_set_tile"):
+        pt.resizeFrameBufferIfNeeded(None, 32768, 32768)  # 1.07 G pixels: 17 G samples per step, 3.3 TB of path state
+        pt.step(None, cam)
+    pt.set_tile(0, 4096)  # a 1/4096 share of it fits
+    pt.resizeFrameBufferIfNeeded(None, 32768, 32768)
+    pt.step(None, cam)
+    assert pt.stats()["samples"] == pt.owned_pixels() * 16
