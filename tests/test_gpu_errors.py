@@ -98,3 +98,48 @@ def test_a_frame_that_cannot_fit_names_the_way_out(mv):
     pt.resizeFrameBufferIfNeeded(None, 32768, 32768)
     pt.step(None, cam)
     assert pt.stats()["samples"] == pt.owned_pixels() * 16
+
+
+def test_inputs_the_reference_never_sees_do_not_fault(mv):
+    """the reference's applications derive origin / dps from the mesh's bounding box and never trace NaN rays; a library is handed anything: a grid
+    that covers part of the mesh or none of it, NaN / inf / degenerate / huge triangles, zero rays, NaN / zero / inf rays, a NaN camera -- every
+    call comes back with a result or an error (tools/robust_probe.py prints the same cases)"""
+    tris = bunny_tris()
+    v = tris.reshape(-1, 3).copy()
+    white, black = np.ones_like(v), np.zeros_like(v)
+    lo = v.min(0)
+    ext = float((v.max(0) - lo).max())
+    res = 64
+
+    def build(vv, origin, dps):
+        s = mv.IntersectorOctreeGPU()
+        s.build(vv, white, black, None, origin, dps, res)
+        return s
+
+    full = build(v, lo, ext / res).info().numberOfVoxels
+    part = build(v, lo + 0.4 * ext, 0.2 * ext / res).info().numberOfVoxels  # the grid covers a corner of the mesh only: clipped
+    assert 0 < part < full
+    with pytest.raises(mv.MvrtError, match="touch no voxel"):
+        build(v, lo + 100 * ext, ext / res)
+    for mutate in (lambda a: a.__setitem__(5, np.nan), lambda a: a.__setitem__((7, 1), np.inf), lambda a: a.__setitem__(slice(3, 6), a[3].copy()),
+                   lambda a: a.__setitem__(slice(9, 12), a[9:12] * 1e30)):
+        vv = v.copy()
+        mutate(vv)
+        n = build(vv, lo, ext / res).info().numberOfVoxels
+        assert abs(int(n) - int(full)) < 64  # the one bad triangle is dropped or clipped, the rest of the mesh is there
+    s = build(v, lo, ext / res)
+    out = s.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert all(len(x) == 0 for x in out.values())
+    ro = np.array([[np.nan, 0, 0], [0, 0, 0], [1e30, 1e30, 1e30], [0, 0, 0]], np.float32)
+    rd = np.array([[1, 0, 0], [0, 0, 0], [1, 1, 1], [np.inf, 1, np.nan]], np.float32)
+    assert (s.intersect(ro, rd)["t"] == np.float32(3.4028235e38)).all()  # all of them miss
+    pt = mv.PathTracer()
+    pt.setup(None)
+    pt.resizeFrameBufferIfNeeded(None, 64, 36)
+    pt.set_hdri_scale(0.0)
+    pt.updateScene(v, white, black, None, lo, ext / res, res)
+    cam = np.array(probe_camera(lo, np.float32(ext / res), res), np.float32, copy=True)
+    cam[:3] = np.nan
+    pt.step(None, cam)
+    fb = pt.read_framebuffer()[: 64 * 36]
+    assert np.isfinite(fb).all() and (fb[:, 3] == 16).all()
