@@ -143,3 +143,48 @@ def test_inputs_the_reference_never_sees_do_not_fault(mv):
     pt.step(None, cam)
     fb = pt.read_framebuffer()[: 64 * 36]
     assert np.isfinite(fb).all() and (fb[:, 3] == 16).all()
+
+
+def test_tiny_frames_empty_tile_shares_and_handle_lifetimes(mv):
+    """1x1 and 3x2 frames, tile shares that own no pixel of a small frame, two path tracers side by side, a handle destroyed with steps in flight, a
+    rebuild between steps (tools/robust_probe2.py prints the same)"""
+    import gc
+    tris = bunny_tris()
+    v = tris.reshape(-1, 3)
+    white, black = np.ones_like(v), np.zeros_like(v)
+    lo = v.min(0)
+    ext = float((v.max(0) - lo).max())
+    res = 64
+    cam = probe_camera(lo, np.float32(ext / res), res)
+
+    def mk(w, h, tile=(0, 1)):
+        pt = mv.PathTracer()
+        pt.setup(None)
+        pt.set_tile(*tile)
+        pt.resizeFrameBufferIfNeeded(None, w, h)
+        pt.set_hdri_scale(0.0)
+        pt.updateScene(v, white, black, None, lo, ext / res, res)
+        return pt
+
+    for w, h, tile, pixels in ((1, 1, (0, 1), 1), (3, 2, (0, 1), 6), (100, 37, (31, 32), 0), (100, 37, (14, 32), 116), (17, 1, (1, 2), 0)):
+        pt = mk(w, h, tile)
+        for _ in range(2):
+            pt.step(None, cam)
+        fb = pt.read_framebuffer()
+        assert pt.owned_pixels() == 256 and int((fb[:, 3] == 32).sum()) == pixels and int((fb[:, 3] == 0).sum()) == 256 - pixels
+        assert pt.stats()["samples"] == pixels * 32 and (pt.stats()["rays"] > 0) == (pixels > 0)
+    a, b = mk(64, 36), mk(48, 27)
+    for _ in range(3):
+        a.step(None, cam)
+        b.step(None, cam)
+    assert a.read_framebuffer()[: 64 * 36, 3].min() == 48 and b.read_framebuffer()[: 48 * 27, 3].min() == 48
+    c = mk(640, 360)
+    for _ in range(5):
+        c.step(None, cam)
+    del c
+    gc.collect()  # destroyed with deferred / in-flight steps
+    d = mk(64, 36)
+    d.step(None, cam)
+    d.updateScene(v, white, black, None, lo, ext / res, 128)
+    d.step(None, cam)
+    assert d.read_framebuffer()[: 64 * 36, 3].min() == 32
