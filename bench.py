@@ -2,7 +2,11 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json): wavefront path tracing of a sparse voxel
 octree at 1920x1080, 64 spp (4 steps of 16 spp), reported as Mrays/s (primary + secondary rays).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid-res R] [--scene dragon|rtcamp]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid-res R] [--scene dragon|rtcamp|cave]
+
+N > 1 without a launcher (`python bench.py --gpus N`): bench.py starts its own ranks -- `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a child process, before this process imports torch or the library -- and relays rank 0's line.  Under an explicit
+torch.distributed.run (WORLD_SIZE set) it is a rank.
 
 A "step" is one PathTracer::step (reference PathTracer.hpp:150-169): 16 spp for every pixel of the frame.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's 256-pixel blocks are dealt
@@ -109,6 +113,39 @@ def stress_traffic(n_rays):
     return int(json.load(open(p))["traffic_bytes_per_ray"] * n_rays)
 
 
+def self_launch_cmd(n, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n):
+    """`python3 bench.py --gpus N` without a launcher: one rank per GPU under torch.distributed.run on a free local port.  Nothing in THIS process
+    has initialised the GPU (no torch, no library import yet), and the ranks are started with subprocess -- never an exec."""
+    import socket
+    import subprocess
+    assert "torch" not in sys.modules and "massivevoxelraytracing_amd" not in sys.modules, "self_launch must run before anything touches the GPU"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this image
+    cmd = self_launch_cmd(n, sys.argv[1:], port)
+    if os.environ.get("MVRT_BENCH_PRINT_LAUNCH") == "1":  # (tests/test_multirank_cpu.py: the command, without running it)
+        print(json.dumps(cmd))
+        return
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in p.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+    if line is None:
+        sys.stdout.write(p.stdout)
+        sys.exit(p.returncode or 1)
+    print(line, flush=True)
+    sys.exit(p.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,14 +172,18 @@ def main():
     if args.grid_res == 0:
         args.grid_res = {"dragon": 2048, "rtcamp": 4096, "cave": 2048}[args.scene] if args.mode != "stress" else 8192
 
+    force_dist = os.environ.get("MVRT_FORCE_DIST") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist) and args.mode == "pt":
+        # plain `python3 bench.py --gpus N`: start the N ranks ourselves -- as a CHILD process, before this process has imported torch or the
+        # library or touched the GPU -- and relay rank 0's JSON line and the exit code (the explicit torch.distributed.run form keeps working)
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch N > 1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`" % (args.gpus, world))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     dist = None
     torch = None
-    force_dist = os.environ.get("MVRT_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         import torch  # noqa: F811  (device memory for the collective + torch.distributed over RCCL)
         import torch.distributed as dist  # noqa: F811
@@ -218,23 +259,26 @@ def main():
         frame = torch.empty(W * H * 4, dtype=torch.float32, device="cuda")
 
     frame_steps = args.frame_steps if args.frame_steps > 0 else max(args.steps, 1)
+    # N > 1: everything of a frame is issued on torch's CURRENT stream (its handle is passed to the library explicitly), which is also the stream
+    # the collective is ordered against -- no reliance on the legacy null stream's implicit ordering
+    ts = torch.cuda.current_stream().cuda_stream if dist is not None else None
 
     def run_steps(k):
         """k steps as frames of `frame_steps` steps (64 spp): per frame clear -> steps -> (N > 1: one RCCL all-gather of the per-rank accumulation
         buffers + assemble) -> the frame is complete on the device.  Everything of a frame is stream-ordered (step() is deferred / pipelined
-        inside the library; join() makes the stream wait for it; torch's collective is ordered behind the current = null stream and
-        the null stream behind it), so the only host synchronisation is the one that ends the frame."""
+        inside the library; join() makes the stream wait for it; N > 1: the d2d copy and the assembly are issued on torch's current stream,
+        which the collective is ordered against), so the only host synchronisation is the one that ends the frame."""
         done = 0
         while done < k:
             n = min(frame_steps, k - done)
-            pt.clearFrameBuffer(None)
+            pt.clearFrameBuffer(ts)
             for _ in range(n):
-                pt.step(None, cam)
-            pt.join(None)
+                pt.step(ts, cam)
+            pt.join(ts)
             if dist is not None:
-                mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16)
+                mv.memcpy_d2d(gather_in, pt.framebuffer_dev(), owned * 16, ts)
                 dist.all_gather_into_tensor(gather_out, gather_in)
-                mv.assemble_tiles(gather_out, world, owned, W, H, frame)
+                mv.assemble_tiles(gather_out, world, owned, W, H, frame, ts)
             mv.synchronize()  # the 64-spp frame is finished: an application would read / resolve it now
             done += n
 
@@ -358,6 +402,7 @@ def main():
             "value": round(rays / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -64,7 +64,12 @@ typedef struct mvrt_svo_info
 	uint32_t gridRes;
 	uint32_t levels;		   /* log2(gridRes) = maximum traversal stack depth */
 	uint64_t totalDumpedVoxels; /* voxels emitted before de-duplication (build only, else 0) */
+	uint32_t flavour;			/* layout behind mvrt_svo_node_buffer_dev: MVRT_FLAVOUR_* */
+	uint32_t reserved;
 } mvrt_svo_info;
+#define MVRT_FLAVOUR_EMBEDDED 0 /* 64-byte lines {children[8] with the child's mask in bits 24-31, nVoxelsPSum[8]} */
+#define MVRT_FLAVOUR_PLAIN 1	/* 64-byte lines {children[8], the 8 child masks in 2 words, 6 unused words}; nVoxelsPSum in a separate array */
+#define MVRT_FLAVOUR_TREE 2		/* 16-byte two-level bricks {u8 childMask[8]; u32 ownMask; u32 base} (four per 64-byte line) */
 
 int mvrt_svo_create( mvrt_svo** out );
 int mvrt_svo_destroy( mvrt_svo* svo ); /* IntersectorOctreeGPU::cleanUp, :26-38 */
@@ -105,13 +110,14 @@ int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info );
 int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale ); /* m_emissionScale (:273) */
 /* bytes of the device structure the traversal and mvrt_svo_download work from (the reference's layout would be numberOfNodes * 68):
  * 64-byte lines per node (+ a 16 MiB prefix table) for DAG octrees; for GPU-built octrees WITHOUT node sharing whose masks are not embedded
- * ("tree" flavour: MVRT_BUILD_NO_DAG with >= 0xFFFFFF nodes or MVRT_BUILD_NO_EMBEDDED_MASK) 5 bytes per node + one 64-byte two-level brick
- * per node of every second level. */
+ * ("tree" flavour: MVRT_BUILD_NO_DAG with >= 0xFFFFFF nodes or MVRT_BUILD_NO_EMBEDDED_MASK) 5 bytes per node + one 16-byte two-level brick
+ * per node of every second level (four bricks share a 64-byte line). */
 uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo );
 /* m_nodeBuffer / m_vAttributeBuffer (:265-266): the device arrays.  Attributes are the reference's VoxelAttirb[numberOfVoxels]; nodes are
  * this library's 64-byte lines {u32 children[8]; u32 nVoxelsPSum[8]} (the reference's 68-byte node minus its leading mask word, which rides
  * in bits 24-31 of the parent's pointer); for an octree too large for that (no node sharing, > 2^24 nodes: the tree flavour) they are its 16-byte
- * two-level bricks {u8 childMask[8]; u32 ownMask; u32 base} -- use mvrt_svo_download for the reference layout. */
+ * two-level bricks {u8 childMask[8]; u32 ownMask; u32 base}.  mvrt_svo_info::flavour says which of the three layouts the pointer has; use
+ * mvrt_svo_download for the reference layout. */
 const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo );
 const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo );
 /* read the SVO back in the reference layout (parity checks of build); either pointer may be NULL */
@@ -235,6 +241,10 @@ typedef struct mvrt_pt_stats
 	double shadeKernelMs;	 /* summed time of shade+compact kernels (profiling on) */
 	double totalKernelMs;	 /* summed time of every kernel of step() (profiling on) */
 } mvrt_pt_stats;
+/* Failure-path testing: when bytes != 0 the path-state budget of resize / set_pipeline_depth / set_batch_steps is computed against this much "free HBM"
+ * instead of what hipMemGetInfo reports.  After a failed (re)allocation the handle has NO frame (steps fail with an error until the next
+ * successful mvrt_pt_resize_framebuffer_if_needed). */
+int mvrt_pt_set_test_free_bytes( mvrt_pt* pt, uint64_t bytes );
 int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled ); /* HIP events on `stream` around each kernel of step(); read by get_stats */
 int mvrt_pt_reset_stats( mvrt_pt* pt );
 int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out ); /* synchronises the stream */

@@ -27,7 +27,7 @@ class MvrtError(RuntimeError):
 
 class SvoInfo(C.Structure):
     _fields_ = [("numberOfNodes", _u32), ("numberOfVoxels", _u32), ("lower", _f32 * 3), ("upper", _f32 * 3), ("dps", _f32), ("emissionScale", _f32),
-                ("hasEmission", _u32), ("embeddedMask", _u32), ("gridRes", _u32), ("levels", _u32), ("totalDumpedVoxels", _u64)]
+                ("hasEmission", _u32), ("embeddedMask", _u32), ("gridRes", _u32), ("levels", _u32), ("totalDumpedVoxels", _u64), ("flavour", _u32), ("reserved", _u32)]
 
 
 class PtStats(C.Structure):
@@ -102,6 +102,7 @@ SIGNATURES = {
     "mvrt_pt_read_sample_radiance": (_i32, [_vp, _vp, _u64]),
     "mvrt_pt_set_debug_capture": (_i32, [_vp, _i32]),
     "mvrt_pt_read_debug_stage": (_i32, [_vp, _i32, _vp, _u64, _vp]),
+    "mvrt_pt_set_test_free_bytes": (_i32, [_vp, _u64]),
     "mvrt_pt_set_profiling": (_i32, [_vp, _i32]),
     "mvrt_pt_reset_stats": (_i32, [_vp]),
     "mvrt_pt_get_stats": (_i32, [_vp, _vp, _vp]),
@@ -487,6 +488,10 @@ class PathTracer:
         n = C.c_uint32(0)
         _check(lib().mvrt_pt_read_debug_stage(self._h, stage, _hp(out), cap, C.byref(n)))
         return out[: n.value].copy()
+
+    def set_test_free_bytes(self, nbytes):
+        """failure-path tests: budget the path state against `nbytes` of free HBM (0 = what the device reports)"""
+        _check(lib().mvrt_pt_set_test_free_bytes(self._h, int(nbytes)))
 
     def set_profiling(self, on):
         _check(lib().mvrt_pt_set_profiling(self._h, int(on)))

@@ -376,6 +376,8 @@ MVRT_EXPORT int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info )
 {
 	REQUIRE( svo && info, "null argument" );
 	*info = svo->info;
+	info->flavour = svo->tree ? MVRT_FLAVOUR_TREE : ( svo->info.embeddedMask ? MVRT_FLAVOUR_EMBEDDED : MVRT_FLAVOUR_PLAIN );
+	info->reserved = 0;
 	return 0;
 }
 MVRT_EXPORT uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo )
@@ -749,6 +751,7 @@ struct mvrt_pt
 	PtBuffers& buf = slots[0].buf; // slot 0 doubles as "the" buffer set for capacity / stats bookkeeping
 	bool setupDone = false;
 	bool profiling = false;
+	uint64_t testFreeBytes = 0; // != 0: allocWork budgets against this instead of hipMemGetInfo (tests of the failure path)
 	bool debugCapture = false; // keep the survivor list of every shade stage of the last pass (mvrt_pt_set_debug_capture)
 	EventProfiler prof;
 	int numCUs = 0;
@@ -921,7 +924,24 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	MVRT_HIP( hipMemcpy( (void*)b.selfDev, &b, sizeof( PtBuffers ), hipMemcpyHostToDevice ) );
 	return 0;
 }
+static int allocWorkInner( mvrt_pt* pt );
+// (Re)allocates the path state of every pipeline slot.  On ANY failure nothing stale is left behind: every slot's buffer table is zeroed (cap = 0, so
+// launchPass refuses to run) and the frame is forgotten (width = height = 0, frame buffer released), so that the next
+// resizeFrameBufferIfNeeded -- same size or not -- allocates again instead of returning early onto freed memory.
 static int allocWork( mvrt_pt* pt )
+{
+	if( allocWorkInner( pt ) == 0 ) return 0;
+	for( mvrt_pt::Slot& sl : pt->slots )
+	{
+		sl.work.release();
+		memset( &sl.buf, 0, sizeof( sl.buf ) );
+	}
+	pt->width = pt->height = 0;
+	pt->fbF32.release();
+	pt->fbU8.release();
+	return 1;
+}
+static int allocWorkInner( mvrt_pt* pt )
 {
 	if( pt->drain() ) return 1;
 	if( !pt->statsBuf.p )
@@ -935,9 +955,14 @@ static int allocWork( mvrt_pt* pt )
 	// must fit beside the octree: when it would take more than 70 % of the HBM that is free right now, merge fewer steps per pass first, then
 	// keep fewer passes in flight.  Results do not depend on either.
 	{
-		for( mvrt_pt::Slot& sl : pt->slots ) sl.work.release(); // (what is allocated now is about to be replaced)
+		for( mvrt_pt::Slot& sl : pt->slots ) // (what is allocated now is about to be replaced)
+		{
+			sl.work.release();
+			memset( &sl.buf, 0, sizeof( sl.buf ) ); // no pointer into the freed block survives a failure below
+		}
 		size_t freeB = 0, totalB = 0;
 		MVRT_HIP( hipMemGetInfo( &freeB, &totalB ) );
+		if( pt->testFreeBytes ) freeB = (size_t)pt->testFreeBytes; // mvrt_pt_set_test_free_bytes: pretend this much HBM is free (failure-path tests)
 		pt->batchCap = MVRT_MAX_BATCH;
 		pt->depth = pt->depthWanted;
 		const uint64_t budget = (uint64_t)( 0.7 * (double)freeB );
@@ -1318,6 +1343,12 @@ MVRT_EXPORT int mvrt_pt_read_debug_stage( mvrt_pt* pt, int stage, uint32_t* task
 	return 0;
 }
 
+MVRT_EXPORT int mvrt_pt_set_test_free_bytes( mvrt_pt* pt, uint64_t bytes )
+{
+	REQUIRE( pt, "null argument" );
+	pt->testFreeBytes = bytes;
+	return 0;
+}
 MVRT_EXPORT int mvrt_pt_set_profiling( mvrt_pt* pt, int enabled )
 {
 	REQUIRE( pt, "null argument" );

@@ -663,8 +663,8 @@ __global__ void __launch_bounds__( BB ) kMakeNodesDirect( const Task* __restrict
 // ---- "tree" flavour (no DAG and too many nodes for embedded masks, or embedding switched off): the nodes are never materialised as 64-byte
 // lines.  In a tree built level by level in morton order the children of a node are CONSECUTIVE nodes of the level below, so a node is
 // { mask, index of its first child } (5 bytes; for the parents of voxels: index of their first voxel), and what the traversal reads are
-// BRICKS: one 64-byte line per node of every second level holding, for each of its 8 children, the child's mask and where the child's own
-// children start -- a line fetch advances the traversal TWO levels (traverse_stream.h, flavour 2). -------------------------------------------
+// BRICKS: one 16-byte record per node of every second level { the masks of its 8 children, its own mask, where the children of its first
+// child start } (four bricks share a 64-byte line) -- one fetch advances the traversal TWO levels (traverse_stream.h, flavour 2). ------------
 __global__ void __launch_bounds__( BB ) kMakeNodesTree( const Task* __restrict__ tasks, uint64_t n, const uint32_t* __restrict__ blockOff, uint32_t nodeBase, int bottomLevel,
 														 uint8_t* __restrict__ cMask, uint32_t* __restrict__ cFirst, Task* __restrict__ tasksOut )
 {

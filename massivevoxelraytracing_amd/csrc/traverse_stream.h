@@ -2,11 +2,11 @@
 //
 // Three node-reference flavours (template parameter FL; EMBED = FL == 0, TREE = FL == 2):
 //   FL = 2 (tree) : octrees WITHOUT node sharing whose masks cannot be embedded (the HBM-resident 8192^3 stress octree).  The children of a
-//                   node are consecutive nodes, so a child reference is (first child, mask) and the traversal reads two-level BRICKS: the
-//                   64-byte line of a node on every second level holds, per child, the child's mask and where the child's children start.
-//                   A lane sitting on a brick root keeps (brick index, own mask); descending fetches (child mask, first grandchild) from the
-//                   line it already touched, and only the next descent -- onto the grandchild's brick, index = first + popcount(mask below) --
-//                   is a new line.  One dependent HBM fetch per TWO levels; the hit voxel's index falls out of the last step
+//                   node are consecutive nodes, so a child reference is (first child, mask) and the traversal reads two-level BRICKS: a
+//                   16-byte record per node of every second level { u8 childMask[8]; u32 ownMask; u32 base } (four share a 64-byte line).
+//                   A lane sitting on a brick root keeps the whole record in registers; descending into child c is arithmetic
+//                   (base + popcount of the child masks before c), and only the next descent -- onto the grandchild's brick -- is a new
+//                   fetch.  One dependent HBM fetch per TWO levels; the hit voxel's index falls out of the last step
 //                   (first voxel + popcount), so no nVoxelsPSum walk and no voxel path either.  svo_build.hip (kMakeBricks) builds them.
 //   FL = 0 (EMBED): child pointers carry the child's occupancy mask in bits 24-31 (ENABLE_EMBEDED_MASK,
 //                   voxCommon.hpp:7-9); < 2^24 nodes; node offsets fit 32 bits.

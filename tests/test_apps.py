@@ -187,3 +187,19 @@ def test_bench_rccl_branch_runs_on_one_gpu():
     line = json.loads(out.strip().split("\n")[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["gather_ok"] is True
     assert "RCCL" in line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus N` with NO launcher and no WORLD_SIZE: bench.py starts torch.distributed.run itself (a child process, before it touches
+    the GPU) and relays rank 0's line.  Driven here with N = 1 + MVRT_FORCE_DIST=1 (a box has one GPU): the RCCL gather path runs and every
+    rank finds its pixels in the assembled frame."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MVRT_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--width", "640", "--height", "360", "--grid-res", "512",
+                                   "--detail", "0.25", "--no-cpu-baseline"], env=env, timeout=900).decode()
+    line = json.loads(out.strip().split("\n")[-1])
+    assert line["n_gpus"] == 1 and line["n_ranks_seen"] == 1 and line["value"] > 0 and line["config"]["gather_ok"] is True
+    assert "RCCL" in line["config"]["parallelism"]

@@ -100,6 +100,43 @@ def test_a_frame_that_cannot_fit_names_the_way_out(mv):
     assert pt.stats()["samples"] == pt.owned_pixels() * 16
 
 
+def test_a_reallocation_that_fails_leaves_no_stale_buffers(mv):
+    """a frame is allocated, then a RE-allocation at the same frame size fails (deeper pipeline / bigger batch against a pretended
+    smaller free HBM).  The handle must not keep pointers into the freed path state: step() returns an error (no launch onto freed memory), a
+    resize at the very same size allocates again, and the frame then renders exactly what an untouched handle renders."""
+    def fresh():
+        pt = mv.PathTracer()
+        pt.setup(None)
+        pt.m_intersectorOctreeGPU.build_synthetic(64, 5000, seed=3)
+        pt.set_hdri_scale(0.0)
+        return pt
+    cam = probe_camera(np.zeros(3, np.float32), np.float32(1.0 / 64), 64)
+    w, h = 256, 128
+    ref = fresh()
+    ref.resizeFrameBufferIfNeeded(None, w, h)
+    ref.step(None, cam)
+    want = ref.read_framebuffer()
+
+    pt = fresh()
+    pt.set_pipeline_depth(1)
+    pt.set_batch_steps(1)
+    pt.resizeFrameBufferIfNeeded(None, w, h)
+    pt.step(None, cam)
+    assert np.array_equal(pt.read_framebuffer(), want)
+    per_pass = w * h * 16 * 190
+    pt.set_test_free_bytes(int(per_pass * 0.5))  # pretend: not even one pass of one step fits the free HBM
+    with pytest.raises(mv.MvrtError, match="mvrt_pt_set_tile"):
+        pt.set_pipeline_depth(2)  # re-allocates the path state at the unchanged frame size: releases what is there, then fails its budget
+    with pytest.raises(mv.MvrtError):
+        pt.step(None, cam)  # no frame any more: an error, not a launch onto freed buffers
+    with pytest.raises(mv.MvrtError):
+        pt.resizeFrameBufferIfNeeded(None, w, h)  # same size, still no room: fails again (does NOT return early as "nothing to do")
+    pt.set_test_free_bytes(0)
+    pt.resizeFrameBufferIfNeeded(None, w, h)  # same size, room again: allocates
+    pt.step(None, cam)
+    assert np.array_equal(pt.read_framebuffer(), want)
+
+
 def test_inputs_the_reference_never_sees_do_not_fault(mv):
     """the reference's applications derive origin / dps from the mesh's bounding box and never trace NaN rays; a library is handed anything: a grid
     that covers part of the mesh or none of it, NaN / inf / degenerate / huge triangles, zero rays, NaN / zero / inf rays, a NaN camera -- every

@@ -55,3 +55,18 @@ def test_two_rank_gather_assembles_full_frame(w, h):
         assert np.array_equal(f[:, 0], idx.astype(np.float32))
         assert np.array_equal(f[:, 1], ((idx * 7) % 13).astype(np.float32))
         assert (f[:, 3] == 16.0).all()
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` with no launcher: bench.py starts `torch.distributed.run --nproc-per-node N bench.py ...` as a child, before it
+    imports torch or the library (checked by an assert in self_launch); here only the command is printed (no GPU in the CPU suite)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MVRT_BENCH_PRINT_LAUNCH"] = "1"
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "8", "--warmup", "2"], env=env, timeout=120).decode()
+    cmd = json.loads(out.strip().split("\n")[-1])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "8", "--warmup", "2"]
