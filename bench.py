@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--frame-steps", type=int, default=4, help="steps per frame: 4 = the metric's 64 spp.  The K timed steps are rendered as frames of this many steps, the "
                     "frame buffer cleared and the device synchronised between frames, so `value` is the 64-spp figure whatever K is (0 = one frame of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hints", action="store_true", help="A/B: every ray starts at the root (PathTracer.set_origin_hints(False)); results are identical")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra non-overlapped pass the roofline numbers come from")
     ap.add_argument("--serial-only", action="store_true", help="run ONLY the non-overlapped pass (pipeline depth 1, batch 1): the command profiles/ *_serial_kernel_stats.csv is taken from")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -215,6 +216,8 @@ def main():
     pt.setup(None)
     pt.set_tile(rank, world) if not args.emulate_tiles else pt.set_tile(0, args.emulate_tiles)
     pt.resizeFrameBufferIfNeeded(None, W, H)
+    if args.no_hints:
+        pt.set_origin_hints(False)
     hdr = os.path.join(ROOT, "tests", "golden", "monks_forest_s.hdr")
     pt.loadHDRI(None, hdr, hdr)
     t_build = time.time()

@@ -131,6 +131,15 @@ int mvrt_svo_download( const mvrt_svo* svo, void* nodes68Host, void* attribs8Hos
  * algorithmic-bytes model in DESIGN.md. */
 int mvrt_trace_batch( const mvrt_svo* svo, uint64_t n, const float* roxDev, const float* royDev, const float* rozDev, const float* rdxDev, const float* rdyDev,
 					  const float* rdzDev, const uint8_t* isShadowDev, float* tDev, int32_t* nMajorDev, uint32_t* vIndexDev, uint32_t* descentsDev, void* stream );
+/* Same with a START HINT per ray (new; no counterpart in the reference, which starts every ray at the root, voxCommon.hpp:306-312):
+ * originVoxelMortonDev[i] = the 3-bits-per-level root->voxel path (= Morton code of the grid cell, x = bit 0) of ANY voxel that exists in the
+ * octree, or ~0 for "no hint".  The traversal replays the walk from the root along that path arithmetically for as long as the ray's origin lies
+ * in the same octants and starts below the root; every output, descents included, is identical to the unhinted call for every valid hint -- a
+ * hint near the origin only makes it cheaper (the path tracer hints each secondary ray with the voxel its path just hit).  Embedded-mask
+ * octrees only; ignored otherwise.  A code that names a cell WITHOUT a voxel is an error the library does not detect. */
+int mvrt_trace_batch_hinted( const mvrt_svo* svo, uint64_t n, const float* roxDev, const float* royDev, const float* rozDev, const float* rdxDev, const float* rdyDev,
+							 const float* rdzDev, const uint8_t* isShadowDev, const uint64_t* originVoxelMortonDev, float* tDev, int32_t* nMajorDev, uint32_t* vIndexDev,
+							 uint32_t* descentsDev, void* stream );
 /* convenience: packed host arrays (n*3 floats), synchronous */
 int mvrt_trace_batch_host( const mvrt_svo* svo, uint64_t n, const float* roHost, const float* rdHost, const uint8_t* isShadowHost, float* tHost, int32_t* nMajorHost,
 						   uint32_t* vIndexHost, uint32_t* descentsHost );
@@ -186,6 +195,9 @@ int mvrt_pt_step_matrices( mvrt_pt* pt, void* stream, const float view[16], cons
  * first makes `stream` wait for the steps in flight; callers that read mvrt_pt_framebuffer_dev() themselves call
  * mvrt_pt_join( pt, stream ) before. */
 int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth );
+/* Secondary rays (shadow, extra, bounce) start below the root, hinted with the voxel their path hit last (mvrt_trace_batch_hinted); default on.
+ * 0 = every ray walks from the root like the reference's.  Results are identical either way. */
+int mvrt_pt_set_origin_hints( mvrt_pt* pt, int enable );
 /* step() is DEFERRED: up to maxSteps (1 = launch immediately; 0 = automatic, the default: about two full-HD steps of samples per pass) consecutive step() calls are merged into one
  * wavefront pass -- larger launches, identical per-sample results, additions to the frame buffer still step by step.
  * Any consumer (resolve, to_image, read, clear, join, get_stats ...) launches what is pending first. */

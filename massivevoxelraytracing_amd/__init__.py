@@ -64,6 +64,7 @@ SIGNATURES = {
     "mvrt_pt_download_pmj": (_i32, [_vp, _vp]),
     "mvrt_svo_download": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "mvrt_trace_batch": (_i32, [_vp, _u64] + [_vp] * 11 + [_vp]),
+    "mvrt_trace_batch_hinted": (_i32, [_vp, _u64] + [_vp] * 12 + [_vp]),
     "mvrt_trace_batch_host": (_i32, [_vp, _u64] + [_vp] * 7),
     "mvrt_render_primary": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvrt_camera_from_matrices": (_i32, [_vp, _vp, _f32, _f32, _vp]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "mvrt_pt_step": (_i32, [_vp, _vp, _vp]),
     "mvrt_pt_step_matrices": (_i32, [_vp, _vp, _vp, _vp, _f32, _f32]),
     "mvrt_pt_set_pipeline_depth": (_i32, [_vp, _i32]),
+    "mvrt_pt_set_origin_hints": (_i32, [_vp, _i32]),
     "mvrt_pt_set_batch_steps": (_i32, [_vp, _i32]),
     "mvrt_pt_set_split_small_passes": (_i32, [_vp, _i32]),
     "mvrt_pt_join": (_i32, [_vp, _vp]),
@@ -316,6 +318,19 @@ class IntersectorOctreeGPU:
     def intersect_device(self, n, rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, vIndex, descents=None, stream=None):
         _check(lib().mvrt_trace_batch(self._h, n, *[_dev_ptr(a) for a in (rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, vIndex, descents)], stream))
 
+    def intersect_hinted(self, ro, rd, origin_voxel_morton, isShadowRay=None):
+        """mvrt_trace_batch_hinted on packed host arrays: per ray the Morton code of an EXISTING voxel (or 2^64-1 = no hint) to start below the root from"""
+        ro = np.ascontiguousarray(ro, np.float32).reshape(-1, 3)
+        rd = np.ascontiguousarray(rd, np.float32).reshape(-1, 3)
+        n = len(ro)
+        dev = [DeviceArray.from_host(np.ascontiguousarray(a)) for a in (ro[:, 0], ro[:, 1], ro[:, 2], rd[:, 0], rd[:, 1], rd[:, 2])]
+        sh = None if isShadowRay is None else DeviceArray.from_host(np.ascontiguousarray(isShadowRay, np.uint8))
+        hint = DeviceArray.from_host(np.ascontiguousarray(origin_voxel_morton, np.uint64))
+        t, nm, vi, de = DeviceArray(n, np.float32), DeviceArray(n, np.int32), DeviceArray(n, np.uint32), DeviceArray(n, np.uint32)
+        _check(lib().mvrt_trace_batch_hinted(self._h, n, *[_dev_ptr(a) for a in dev], _dev_ptr(sh), hint.ptr, t.ptr, nm.ptr, vi.ptr, de.ptr, None))
+        synchronize()
+        return {"t": t.to_host(), "nMajor": nm.to_host(), "vIndex": vi.to_host(), "descents": de.to_host()}
+
     def render(self, camera, width, height, showVertexColor=False, want_hits=True, stream=None):
         """the `render` kernel launch of voxRTGPU.cpp:191-203; returns host arrays"""
         cam = np.ascontiguousarray(camera, np.float32)
@@ -434,6 +449,9 @@ class PathTracer:
 
     def set_split_small_passes(self, enable):
         _check(lib().mvrt_pt_set_split_small_passes(self._h, 1 if enable else 0))
+
+    def set_origin_hints(self, enable):
+        _check(lib().mvrt_pt_set_origin_hints(self._h, 1 if enable else 0))
 
     def set_pipeline_depth(self, depth):
         _check(lib().mvrt_pt_set_pipeline_depth(self._h, depth))

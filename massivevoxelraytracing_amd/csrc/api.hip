@@ -11,6 +11,7 @@
 
 #include "../../include/mvrt.h"
 #include "launch.h"
+#include "traverse_stream.h" // (hint geometry: hintTabLevelsOf, prefixTabEntries)
 
 #define MVRT_EXPORT extern "C" __attribute__( ( visibility( "default" ) ) )
 
@@ -241,8 +242,12 @@ static int buildTopTable( mvrt_svo* s, hipStream_t st )
 	s->kids.release();
 	s->topLevels = 0;
 	if( !s->info.embeddedMask || !s->nodes || s->info.levels == 0 ) return 0;
-	if( s->kids.alloc( (uint64_t)s->info.numberOfNodes * 32 ) ) return 1;
+	// children array (32 B per node) + behind it the prefix tables of the start below the root (traverse_stream.h): one buffer, one base register
+	if( s->kids.alloc( (uint64_t)s->info.numberOfNodes * 32 + prefixTabEntries( s->info.levels ) * 4 ) ) return 1;
 	if( launchCopyKids( s->nodes, s->info.numberOfNodes, s->kids.as<uint32_t>(), st ) ) return 1;
+	if( launchBuildPrefixRefs( s->kids.as<uint32_t>(), ( s->info.numberOfNodes - 1 ) | ( (uint32_t)s->rootMask << 24 ), hintTabLevelsOf( s->info.levels ),
+							   s->kids.as<uint32_t>() + (uint64_t)s->info.numberOfNodes * 8, st ) )
+		return 1;
 	static const int envK = getenv( "MVRT_TOP_LEVELS" ) ? atoi( getenv( "MVRT_TOP_LEVELS" ) ) : 7;
 	uint32_t k = (uint32_t)( envK < 0 ? 0 : ( envK > 8 ? 8 : envK ) );
 	if( k > s->info.levels ) k = s->info.levels;
@@ -431,6 +436,17 @@ MVRT_EXPORT int mvrt_trace_batch( const mvrt_svo* svo, uint64_t n, const float* 
 	REQUIRE( tDev, "mvrt_trace_batch: t output is required" );
 	if( svo->ensureWorkspace( vIndexDev ? n : 0 ) ) return 1;
 	return launchTraceBatch( svo->dev(), svo->ws, n, roxDev, royDev, rozDev, rdxDev, rdyDev, rdzDev, isShadowDev, tDev, nMajorDev, vIndexDev, descentsDev, (hipStream_t)stream );
+}
+
+MVRT_EXPORT int mvrt_trace_batch_hinted( const mvrt_svo* svo, uint64_t n, const float* roxDev, const float* royDev, const float* rozDev, const float* rdxDev, const float* rdyDev,
+										 const float* rdzDev, const uint8_t* isShadowDev, const uint64_t* originVoxelMortonDev, float* tDev, int32_t* nMajorDev, uint32_t* vIndexDev,
+										 uint32_t* descentsDev, void* stream )
+{
+	REQUIRE( svo && svo->nodes, "mvrt_trace_batch_hinted: no octree (build or upload first)" );
+	REQUIRE( tDev, "mvrt_trace_batch_hinted: t output is required" );
+	if( svo->ensureWorkspace( vIndexDev ? n : 0 ) ) return 1;
+	return launchTraceBatch( svo->dev(), svo->ws, n, roxDev, royDev, rozDev, rdxDev, rdyDev, rdzDev, isShadowDev, tDev, nMajorDev, vIndexDev, descentsDev, (hipStream_t)stream,
+							 originVoxelMortonDev );
 }
 
 MVRT_EXPORT int mvrt_trace_batch_host( const mvrt_svo* svo, uint64_t n, const float* roHost, const float* rdHost, const uint8_t* isShadowHost, float* tHost,
@@ -775,6 +791,7 @@ struct mvrt_pt
 	int flush( bool moreStepsFollow = false ); // launch the pending steps (defined below)
 	int launchPass( const CameraPinhole* passCams, int iteration, int nSteps, int traceGridDiv );
 	bool splitSmallPasses = true; // MVRT_SPLIT_SMALL=0 disables (A/B)
+	bool originHints = true;	  // secondary rays start below the root (mvrt_pt_set_origin_hints)
 	int effectiveBatch() const // merged steps per pass, bounded so that one pass stays below ~160 M samples (~30 GB of path state)
 	{
 		uint64_t perStep = ownedPixels * MVRT_SPP_PER_STEP;
@@ -887,9 +904,9 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 {
 	const uint64_t cap = pt->ownedPixels * MVRT_SPP_PER_STEP * pt->effectiveBatch();
 	const uint64_t nBlocks = cap / 256 + 8; // (+ padding: the scan reads whole 16-byte quads)
-	// 2 path sets x 16 arrays + 6 direction arrays + hitT + 3 sample-radiance arrays + 2 x 8-byte path arrays,
+	// 2 path sets x 17 arrays + 6 direction arrays + hitT + 3 sample-radiance arrays + 2 x 8-byte path arrays,
 	// 4 bytes per word; 3 byte arrays; every array is padded to 256 B so the float4 reads of Ls* stay aligned
-	const uint64_t words = cap * ( 32 + 6 + 1 + 3 + 4 );
+	const uint64_t words = cap * ( 34 + 6 + 1 + 3 + 4 );
 	const uint64_t bytes = words * 4 + cap * 3 + nBlocks * 4 + 64 * 4 + 32 * 8 + 1024 + 64 * 256;
 	if( sl.work.alloc( bytes ) ) return 1;
 	uint8_t* base = (uint8_t*)sl.work.p;
@@ -904,6 +921,7 @@ static int allocWorkSlot( mvrt_pt* pt, mvrt_pt::Slot& sl )
 	{
 		PathSet& ps = b.set[s];
 		ps.task = (uint32_t*)take( cap * 4 );
+		ps.org = (uint32_t*)take( cap * 4 );
 		float** f[] = { &ps.rox, &ps.roy, &ps.roz, &ps.rdx, &ps.rdy, &ps.rdz, &ps.Tx, &ps.Ty, &ps.Tz, &ps.Lx, &ps.Ly, &ps.Lz, &ps.nx, &ps.ny, &ps.nz };
 		for( float** q : f ) *q = (float*)take( cap * 4 );
 	}
@@ -966,7 +984,7 @@ static int allocWorkInner( mvrt_pt* pt )
 		pt->batchCap = MVRT_MAX_BATCH;
 		pt->depth = pt->depthWanted;
 		const uint64_t budget = (uint64_t)( 0.7 * (double)freeB );
-		auto need = [&]() { return (uint64_t)pt->depth * pt->ownedPixels * MVRT_SPP_PER_STEP * (uint64_t)pt->effectiveBatch() * 190ull; };
+		auto need = [&]() { return (uint64_t)pt->depth * pt->ownedPixels * MVRT_SPP_PER_STEP * (uint64_t)pt->effectiveBatch() * 200ull; };
 		while( need() > budget && pt->effectiveBatch() > 1 ) pt->batchCap = pt->effectiveBatch() - 1;
 		while( need() > budget && pt->depth > 1 ) pt->depth--;
 		REQUIRE( need() <= budget, "frame of %llu owned pixels needs %.1f GB of path state, %.1f GB of HBM are free (split the frame into tiles: mvrt_pt_set_tile)",
@@ -1204,6 +1222,7 @@ int mvrt_pt::launchPass( const CameraPinhole* passCams, int iteration, int nStep
 	f.iteration = iteration;
 	f.nSteps = nSteps;
 	f.traceGridDiv = traceGridDiv;
+	f.useHints = originHints ? 1 : 0;
 	CameraPinhole cams[MVRT_MAX_BATCH];
 	for( int b = 0; b < f.nSteps; b++ ) cams[b] = passCams[b];
 	hipStream_t user = pendingStream;
@@ -1301,6 +1320,13 @@ MVRT_EXPORT int mvrt_pt_set_split_small_passes( mvrt_pt* pt, int enable )
 	REQUIRE( pt, "null argument" );
 	if( pt->drain() ) return 1;
 	pt->splitSmallPasses = enable != 0;
+	return 0;
+}
+MVRT_EXPORT int mvrt_pt_set_origin_hints( mvrt_pt* pt, int enable )
+{
+	REQUIRE( pt, "null argument" );
+	if( pt->flush() ) return 1;
+	pt->originHints = enable != 0;
 	return 0;
 }
 MVRT_EXPORT int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth )

@@ -38,10 +38,17 @@ struct BatchIO
 	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
 	uint32_t utilMaxRayIters = 0;
 #endif
-	MVRT_DI bool load( uint32_t i, f3* ro, f3* rd ) const
+	const uint64_t* originPath; // optional: per ray, the full path of an existing voxel (start-below-the-root hint), ~0 = none
+	uint32_t levels;
+	MVRT_DI bool load( uint32_t i, f3* ro, f3* rd, uint32_t* hint ) const
 	{
 		*ro = mk3( rox[i], roy[i], roz[i] );
 		*rd = mk3( rdx[i], rdy[i], rdz[i] );
+		if( originPath )
+		{
+			const uint64_t op = originPath[i];
+			if( op != ~0ull ) *hint = hintFromVoxelPath( op, levels );
+		}
 		return isShadow ? isShadow[i] != 0 : false;
 	}
 	MVRT_DI void store( uint32_t i, const StreamHit& h, bool ) const
@@ -101,7 +108,7 @@ struct PrimaryIO
 	uint32_t utilMaxRayIters = 0;
 #endif
 	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
-	MVRT_DI bool load( uint32_t pixelIdx, f3* ro, f3* rd )
+	MVRT_DI bool load( uint32_t pixelIdx, f3* ro, f3* rd, uint32_t* )
 	{
 		int x = (int)( pixelIdx % W );
 		int y = (int)( pixelIdx / W );
@@ -204,7 +211,7 @@ static int numCUs()
 }
 
 int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy,
-					  const float* rdz, const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream )
+					  const float* rdz, const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream, const uint64_t* originPath )
 {
 	if( n == 0 ) return 0;
 	if( ws.spill )
@@ -216,6 +223,8 @@ int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, c
 			return 1;
 		}
 		BatchIO io = { rox, roy, roz, rdx, rdy, rdz, isShadow, t, nMajor, paths, descents };
+		io.originPath = svo.embedded ? originPath : nullptr;
+		io.levels = svo.levels;
 		int grid = streamGridKnown( n, numCUs() );
 		MVRT_HIP( hipMemsetAsync( ws.cursor, 0, 8, stream ) );
 		if( svo.embedded ) hipLaunchKernelGGL( kTraceBatchStream<0>, dim3( grid ), dim3( 64 ), 0, stream, svo, n, io, ws, streamChunk( n, grid ) );
@@ -402,6 +411,7 @@ struct PtParams
 	PtBuffers buf;
 	int hdriEnabled;  // hdri.isEnabled(), renderCommon.hpp:467-470
 	int extraSamples; // nSampleExtraDirect = hasEmission ? 1 : 0, voxKernel.cu:721
+	int useHints;	  // secondary rays start below the root (traverse_stream.h); 0 = every ray from the root (A/B, tests)
 };
 
 // owned (local) pixel -> global pixel index.  Blocks of 256 pixels dealt round-robin over tiles.
@@ -479,6 +489,7 @@ struct PtIO
 	int setIdx;
 	uint32_t n;
 	int shadowKind;
+	int useHint; // stage > 0 on an embedded-mask octree: PathSet::org holds the start-below-the-root hint of every path
 #ifdef MVRT_UTIL_STATS
 	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
 	uint32_t utilMaxRayIters = 0;
@@ -490,13 +501,14 @@ struct PtIO
 		*i = r - ( kindSlot == 0u ? 0u : ( kindSlot == 1u ? n : 2u * n ) ); // (no integer multiply: quarter rate)
 		return kindSlot == 0 ? 0 : ( kindSlot == 1 ? ( shadowKind ? 1 : 2 ) : 2 );
 	}
-	MVRT_DI bool load( uint32_t r, f3* ro, f3* rd ) const
+	MVRT_DI bool load( uint32_t r, f3* ro, f3* rd, uint32_t* hint ) const
 	{
 		const __attribute__( ( address_space( 4 ) ) ) PtBuffers& buf = *opaquePtr( table );
 		const __attribute__( ( address_space( 4 ) ) ) PathSet& in = buf.set[setIdx];
 		uint32_t i;
 		const int kind = kindOf( r, &i );
 		*ro = mk3( in.rox[i], in.roy[i], in.roz[i] );
+		if( useHint ) *hint = in.org[i]; // every ray of a path starts on the voxel the path hit last
 		if( kind == 0 ) *rd = mk3( in.rdx[i], in.rdy[i], in.rdz[i] );
 		else if( kind == 1 ) *rd = mk3( buf.sx[i], buf.sy[i], buf.sz[i] );
 		else *rd = mk3( buf.ex[i], buf.ey[i], buf.ez[i] );
@@ -540,6 +552,7 @@ __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kPtTraceStream( PtP
 	io.setIdx = setIdx;
 	io.n = P.buf.liveCount[stage];
 	io.shadowKind = shadowKind;
+	io.useHint = ( FL == 0 && stage > 0 && P.useHints ) ? 1 : 0;
 	io.dNormal = io.dShadow = io.nHits = 0;
 	const uint64_t total = (uint64_t)io.n * nKinds;
 	// The grid is sized on the host for the upper bound (live counts stay on the device).  A launch with few rays is not throughput- but
@@ -715,6 +728,7 @@ __global__ void __launch_bounds__( CBLOCK, MVRT_SHADE_WAVES ) kPtShade( PtParams
 		const bool valid = i < n;
 		bool alive = false;
 		uint32_t task = 0, vIndex = 0;
+		uint64_t hitPath = 0;
 		int nMajor = 0;
 		float t = MVRT_MAXF;
 		f3 ro, rd, T, L;
@@ -727,7 +741,8 @@ __global__ void __launch_bounds__( CBLOCK, MVRT_SHADE_WAVES ) kPtShade( PtParams
 			nMajor = P.buf.hitN[i];
 			const bool hit = t != MVRT_MAXF;
 			// the persistent traversal reports the hit voxel's path; its index is summed here, all lanes together
-			vIndex = hit ? voxelIndexFromPath( P.svo, P.buf.hitPath[i] ) : 0u;
+			hitPath = hit ? P.buf.hitPath[i] : 0ull;
+			vIndex = hit ? voxelIndexFromPath( P.svo, hitPath ) : 0u;
 			if( stage == 0 )
 			{
 				T = mk3( 1.0f, 1.0f, 1.0f );
@@ -814,6 +829,7 @@ __global__ void __launch_bounds__( CBLOCK, MVRT_SHADE_WAVES ) kPtShade( PtParams
 			f2 u = pmjSample2d( P.pmj, spp, dim++, stream ); // :741-745
 			f3 bdir = sampleLambertian( u.x, u.y, hitN );
 			out.task[j] = task;
+			if( P.svo.embedded ) out.org[j] = hintFromVoxelPath( hitPath, P.svo.levels ); // the rays of the next stage start on this voxel
 			out.rox[j] = hitP.x;
 			out.roy[j] = hitP.y;
 			out.roz[j] = hitP.z;
@@ -877,6 +893,7 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 	P.buf = buf;
 	P.hdriEnabled = ( 0.0f < hdri.scale ) ? 1 : 0;
 	P.extraSamples = svo.hasEmission ? 1 : 0;
+	P.useHints = frame.useHints;
 	if( nCUs <= 0 ) nCUs = numCUs();
 
 	const uint64_t nSamples = frame.validOwnedPixels * MVRT_SPP_PER_STEP * frame.nSteps;

@@ -149,6 +149,35 @@ int launchCopyKids( const Node64* nodes, uint64_t nNodes, uint32_t* kids, hipStr
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
+// prefix tables of the start below the root (traverse_stream.h): one thread per (level l, path prefix p of l levels) walks p from the root through
+// the children array and stores the reference it arrives at (index | mask << 24; 0 when the prefix leaves the octree: never looked up)
+__global__ void __launch_bounds__( 256 ) kBuildPrefixRefs( const uint32_t* __restrict__ kids, uint32_t rootRef, uint32_t tabLevels, uint32_t* __restrict__ table )
+{
+	const uint32_t total = 0x249249u & ( ( 1u << ( 3u * ( tabLevels + 1u ) ) ) - 1u ); // sum of 8^l, l = 0..tabLevels
+	for( uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256 )
+	{
+		uint32_t l = 0;
+		while( ( 0x249249u & ( ( 1u << ( 3u * ( l + 1u ) ) ) - 1u ) ) <= e ) l++; // level of entry e
+		const uint32_t p = e - ( 0x249249u & ( ( 1u << ( 3u * l ) ) - 1u ) );
+		uint32_t ref = rootRef;
+		bool alive = true;
+		for( uint32_t k = 0; k < l && alive; k++ )
+		{
+			const uint32_t c = ( p >> ( 3u * ( l - 1u - k ) ) ) & 7u;
+			if( !( ( ref >> ( 24u + c ) ) & 1u ) ) alive = false;
+			else ref = kids[( ref & 0xFFFFFFu ) * 8u + c];
+			if( ref == MVRT_LEAF ) alive = false; // a voxel: prefixes never reach the voxel level (tabLevels <= levels - 1), but uploaded octrees may be shallower in places
+		}
+		table[e] = alive ? ref : 0u;
+	}
+}
+int launchBuildPrefixRefs( const uint32_t* kids, uint32_t rootRef, uint32_t tabLevels, uint32_t* table, hipStream_t stream )
+{
+	const uint32_t total = 0x249249u & ( ( 1u << ( 3u * ( tabLevels + 1u ) ) ) - 1u );
+	hipLaunchKernelGGL( kBuildPrefixRefs, dim3( cappedGrid( total ) ), dim3( 256 ), 0, stream, kids, rootRef, tabLevels, table );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream )
 {
 	hipLaunchKernelGGL( kBuildTopTable, dim3( cappedGrid( 1ull << ( 3 * k ) ) ), dim3( 256 ), 0, stream, nodes, rootIndex, k, table );

@@ -6,6 +6,7 @@
 struct PathSet // ping-ponged between shade stages (compacted by the writer)
 {
 	uint32_t* task;		   // local sample id = ownedPixel * 16 + localSpp
+	uint32_t* org;		   // stage k>0: start-below-the-root hint = leading levels of the path of the voxel the ray starts on (traverse_stream.h)
 	float *rox, *roy, *roz; // ray origin (stage k>0: the hit point the bounce leaves from)
 	float *rdx, *rdy, *rdz; // ray direction (stage k>0: the Lambert bounce direction)
 	float *Tx, *Ty, *Tz;	// throughput after the last T *= R
@@ -43,6 +44,7 @@ struct PtFrame
 	int iteration;			   // iteration of the first step of this batch
 	int nSteps;				   // consecutive step() calls merged into this wavefront pass (1..MVRT_MAX_BATCH)
 	int traceGridDiv;		   // >1: the traversal launches of this pass take only 1/div of the wave slots (it shares the GPU with a sibling pass)
+	int useHints;			   // secondary rays start below the root
 };
 #define MVRT_MAX_BATCH 8
 
@@ -68,7 +70,7 @@ enum MvrtKernelClass
 };
 
 int launchTraceBatch( const SvoDev& svo, const TraceWorkspace& ws, uint64_t n, const float* rox, const float* roy, const float* roz, const float* rdx, const float* rdy, const float* rdz,
-					  const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream );
+					  const uint8_t* isShadow, float* t, int32_t* nMajor, uint32_t* vIndex, uint32_t* descents, hipStream_t stream, const uint64_t* originPath = nullptr );
 int launchRenderPrimary( const SvoDev& svo, const TraceWorkspace& ws, const CameraPinhole& cam, int W, int H, int showVertexColor, uchar4* rgba, float* t, int32_t* nMajor, uint32_t* vIndex,
 						 uint32_t* descents, hipStream_t stream );
 int launchCompactIndices( const uint8_t* keep, uint64_t n, uint32_t* dstIndex, uint32_t* kept, uint32_t* blockScratch, hipStream_t stream );
@@ -93,6 +95,8 @@ int launchTreeTo68( const uint8_t* masks, const uint32_t* first, const uint32_t*
 					hipStream_t stream );
 int launchCopyKids( const Node64* nodes, uint64_t nNodes, uint32_t* kids, hipStream_t stream ); // embedded flavour: compact children array for the traversal
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream ); // embedded flavour only
+// embedded flavour: node reference (index | mask << 24) per path prefix of 0..tabLevels levels, level l at prefixTabOffset( l ) (traverse_stream.h)
+int launchBuildPrefixRefs( const uint32_t* kids, uint32_t rootRef, uint32_t tabLevels, uint32_t* table, hipStream_t stream );
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 
 // GPU SVO construction (svo_build.hip)

@@ -65,8 +65,32 @@
 #endif
 #define MVRT_RING_OF( FL ) ( ( FL ) == 0 ? MVRT_RING_EMBED : ( ( FL ) == 2 ? MVRT_RING_TREE : 4 ) )
 #ifndef MVRT_REFILL_MIN
-#define MVRT_REFILL_MIN 20 // refill once this many lanes are idle (or all of them)
+#define MVRT_REFILL_MIN 28 // refill once this many lanes are idle (or all of them); 20 until a refill also walked the hint's path (r03: 20 / 28 / 36 -> 67.2 / 65.8 / 70.9 ms per 36 launches)
 #endif
+
+// ---- start below the root (embedded flavour) -------------------------------------------------------------------------------------------
+// The reference starts every ray at the root (voxCommon.hpp:306-312).  A secondary ray of the path tracer starts ON the voxel its path just
+// hit, and for such a ray ~9 of the ~11 first node visits only walk back down to that voxel: at every node on the way the first candidate that is
+// not behind the origin is the octant the origin lies in, and that octant is an ancestor of the hit voxel.  Which octant it is follows from
+// the node's slab times alone -- bit a of the octant = tM_a < max( S, 0 ) (derivation at startBelowRoot) -- so, given the path of ANY voxel
+// that exists (the HINT), the walk is replayed without touching the octree: the same fp32 operations per level as the node-visit step,
+// compared against the hint's child index; it stops at the first level where the two differ (or after MVRT_HINT_MAX levels) and the normal
+// traversal starts THERE, with the skipped ancestors on the stack.  An ancestor is stacked when a later candidate exists geometrically (the
+// reference's own push rule, voxCommon.hpp:368,377-380: a superset of this kernel's "later VALID candidate" rule -- the extra entries pop
+// into visits that find nothing, which changes no result); the node references of the ancestors come from prefix tables (one u32 reference
+// per path prefix of 0..MVRT_HINT_MAX levels, stored behind the children array): independent gathers, no pointer chase.
+// Results -- t, nMajor, the voxel path, and the descents count, to which the skipped levels are added -- are those of the walk from the root
+// for ANY valid hint; a hint is only ever a prefix of the path of an existing voxel.
+#define MVRT_NO_HINT 0xFFFFFFFFu
+#ifndef MVRT_HINT_MAX
+#define MVRT_HINT_MAX 7u // levels a hint carries = deepest prefix table (8^7 entries of 4 bytes); at most the ring's 8 slots
+#endif
+MVRT_HDI uint32_t hintLevelsOf( uint32_t levels ) { return levels == 0u ? 0u : ( levels - 1u < MVRT_HINT_MAX ? levels - 1u : MVRT_HINT_MAX ); }
+MVRT_HDI uint32_t hintTabLevelsOf( uint32_t levels ) { return hintLevelsOf( levels ); }
+MVRT_HDI uint32_t prefixTabOffset( uint32_t l ) { return 0x249249u & ( ( 1u << ( 3u * l ) ) - 1u ); } // (8^l - 1) / 7: entries of the tables of fewer levels
+MVRT_HDI uint64_t prefixTabEntries( uint32_t levels ) { return (uint64_t)prefixTabOffset( hintTabLevelsOf( levels ) + 1u ); }
+// the hint of a ray that starts on the voxel at `path` (a full root -> voxel path, 3 bits per level)
+MVRT_HDI uint32_t hintFromVoxelPath( uint64_t path, uint32_t levels ) { return (uint32_t)( path >> ( 3u * ( levels - hintLevelsOf( levels ) ) ) ); }
 
 struct StreamHit
 {
@@ -372,7 +396,7 @@ MVRT_DI void traceIrregular( const TraceCore& s, float tx1, float ty1, float tz1
 }
 
 // IO concept (ray indices are 32-bit: a launch never exceeds 2^32 rays):
-//   bool load( uint32_t ray, f3* ro, f3* rd )   -> returns isShadowRay
+//   bool load( uint32_t ray, f3* ro, f3* rd, uint32_t* hint )   -> returns isShadowRay; *hint = MVRT_NO_HINT or hintFromVoxelPath( an existing voxel )
 //   void store( uint32_t ray, const StreamHit& h, bool isShadowRay )
 //
 // One loop iteration = (1) refill when enough lanes are idle: first STORE the results those lanes still hold
@@ -490,7 +514,8 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						ray = chunkNext + ( myRank - given );
 						// ---- ray setup, voxCommon.hpp:240-312 ----
 						f3 ro, rd;
-						isShadow = io.load( ray, &ro, &rd );
+						uint32_t hint = MVRT_NO_HINT;
+						isShadow = io.load( ray, &ro, &rd, &hint );
 						float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
 						vMask = 0;
 						if( ix < 0.0f )
@@ -553,6 +578,78 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 							pending = 0;
 							inLds = 0;
 							st = 1u;
+							if( EMBED && hint != MVRT_NO_HINT && !( min3f( tx1, ty1, tz1 ) < 0.0f ) ) // (a box behind the origin: the root visit settles it)
+							{
+								// Start below the root: replay the walk down the hint's path (see the top of this file).  In a first visit with
+								// T = min( t1 ) >= 0 the candidates behind the origin are those ended by a NEGATIVE mid-plane event (kx, ky, kz of the
+								// step below; the "before the first exit" condition of a flip holds for every negative tM once T >= 0), and they are
+								// a prefix of the candidate order; so the first candidate that is not behind has bit a = ( tM_a < S ) | ( tM_a < 0 )
+								// = tM_a < max( S, 0 ).  If that octant is the hint's child it exists, the step would enter it (its exit is >= 0 by the
+								// same inequalities: T stays >= 0 level after level), and a later candidate exists iff an axis whose bit is clear flips
+								// before the first exit event (fX, fY, fZ of the step).
+								// Straight-line code: the level counter is a compile-time constant (the loop is unrolled, at most MVRT_HINT_MAX = 7
+								// levels = ring slots: a refilled lane's ring is empty, so nothing is ever evicted here), the node references of the
+								// hint's ancestors are ONE batch of independent table gathers issued up front (no pointer chase), lanes that have left
+								// the hint's path just stop changing their state.
+								const uint32_t P = hintLevelsOf( s.levelsM1 + 1u );
+								const char* const tab = (const char*)kids + ( ( s.rootIndex + 1u ) << 5 ); // the prefix tables lie behind the children array (32 B per node; root = last node)
+								uint32_t anc[MVRT_HINT_MAX + 1];
+#pragma unroll
+								for( uint32_t L = 1; L <= MVRT_HINT_MAX; L++ )
+									anc[L] = L <= P ? *(const uint32_t*)( tab + ( ( prefixTabOffset( L ) + ( hint >> ( 3u * ( P - L ) ) ) ) << 2 ) ) : 0u;
+								uint32_t k = 0u;
+								bool on = true;
+								anc[0] = node;
+#pragma unroll
+								for( uint32_t L = 0; L < MVRT_HINT_MAX; L++ )
+								{
+									if( L < P && on ) // (L < P is wave-uniform; lanes that have left the hint's path drop out of the rest of the nest)
+									{
+										const float scale = mvrt_u2f( ( 127u - L ) << 23 );
+										const v2f t1yz = { ty1, tz1 };
+										const v2f dtyz = { dty, dtz };
+										const float tx0 = tx1 - dtx * scale; // :317-320, the step's own operations
+										const v2f t0yz = t1yz - dtyz * scale;
+										const float S0 = fmaxf( fmaxf( fmaxf( tx0, t0yz.x ), t0yz.y ), 0.0f );
+										const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
+										const v2f tMyz = ( t0yz + t1yz ) * 0.5f;
+										const bool bx = txM < S0, by = tMyz.x < S0, bz = tMyz.y < S0;
+										const uint32_t b = ( bx ? 1u : 0u ) | ( by ? 2u : 0u ) | ( bz ? 4u : 0u );
+										on = ( b ^ vMask ) == ( ( hint >> ( 3u * ( P - 1u - L ) ) ) & 7u ); // the origin's octant is the hint's child: it exists, the step enters it
+										if( on )
+										{
+											const bool later = ( (int)!bx & (int)( txM <= minF( ty1, tz1 ) ) ) | ( (int)!by & (int)( tMyz.x < tx1 ) & (int)( tMyz.x <= tz1 ) ) | ( (int)!bz & (int)( tMyz.y < minF( tx1, ty1 ) ) );
+											if( later ) // stack the ancestor (:377-380); its exit times carry the octant it is left through, like any entry
+											{
+												// (the node reference -- word 0 -- is filled in after the walk, when the table gathers have landed: their
+												// latency hides behind this arithmetic instead of stalling the wave at the first level)
+												LdsU32* const w = (LdsU32*)( myRing + L * 64 );
+												w[1] = mvrt_f2u( tx1 ) | ( bx ? 0x80000000u : 0u ); // (T >= 0: the sign bits are free)
+												w[2] = mvrt_f2u( ty1 ) | ( by ? 0x80000000u : 0u );
+												w[3] = mvrt_f2u( tz1 ) | ( bz ? 0x80000000u : 0u );
+												pending |= 1u << L;
+											}
+											tx1 = bx ? tx1 : txM; // :382-386
+											ty1 = by ? ty1 : tMyz.x;
+											tz1 = bz ? tz1 : tMyz.y;
+											k = L + 1u;
+										}
+									}
+								}
+#pragma unroll
+								for( uint32_t L = 0; L < MVRT_HINT_MAX; L++ )
+								{
+									if( L < P )
+									{
+										if( pending & ( 1u << L ) ) *(LdsU32*)( myRing + L * 64 ) = anc[L];
+										node = k == L + 1u ? anc[L + 1] : node;
+									}
+								}
+								inLds = pending;
+								level = k;
+								path = k ? (uint64_t)( hint >> ( 3u * ( P - k ) ) ) : 0ull;
+								descents = k; // the reference fetched one child pointer per level (:381)
+							}
 						}
 					}
 					given += take;
@@ -588,150 +685,6 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			}
 		}
 #endif
-#ifdef MVRT_CANDIDATE_STEP // the round's earlier step: one candidate child per iteration (kept for A/B; 3.5 % slower)
-		// ---------------- (2) traversal steps until enough lanes are idle again ----------------
-		// (a clean inner loop: the per-lane state stays in the same registers from one step to the next)
-		for( ;; )
-		{
-		if( st == 1u )
-		{
-			// y and z ride in one register pair so that the slab arithmetic issues as packed fp32 (v_pk_mul_f32 / v_pk_add_f32:
-			// two IEEE operations per issue slot, each rounded exactly like its scalar twin; no contraction)
-			const float scale = mvrt_u2f( ( 127u - level ) << 23 );
-			const v2f t1yz = { ty1, tz1 };
-			const v2f dtyz = { dty, dtz };
-			const float tx0 = tx1 - dtx * scale; // :317-320
-			const v2f t0yz = t1yz - dtyz * scale;
-			const float ty0 = t0yz.x, tz0 = t0yz.y;
-			// no NaNs can reach here (the direction clamp keeps every product finite), so max3/min3 equal the
-			// reference's compare-select chains up to the sign of a zero, which no decision below can see
-			const float S = fmaxf( fmaxf( tx0, ty0 ), tz0 );
-			const float txM = 0.5f * ( tx0 + tx1 ); // :338-340
-			const v2f tMyz = ( t0yz + t1yz ) * 0.5f;
-			const float tyM = tMyz.x, tzM = tMyz.y;
-			// first visit: childMask bit = (tM < S) = sign bit of (tM - S)  (:342-348; the difference of two
-			// distinct floats is never zero with denormals on, and x - x = +0)
-			const v2f dMyz = tMyz - S;
-			const uint32_t cmInit = ( mvrt_f2u( txM - S ) >> 31 ) | ( ( mvrt_f2u( dMyz.x ) >> 30 ) & 2u ) | ( ( mvrt_f2u( dMyz.y ) >> 29 ) & 4u );
-			const uint32_t cm = bfi( bitMask( childMask, 3 ), cmInit, childMask ); // childMask is either 8 (first visit) or a 3-bit mask
-			const float x1 = mvrt_u2f( bfi( bitMask( cm, 0 ), mvrt_f2u( tx1 ), mvrt_f2u( txM ) ) ); // :358-360
-			const float y1 = mvrt_u2f( bfi( bitMask( cm, 1 ), mvrt_f2u( ty1 ), mvrt_f2u( tyM ) ) );
-			const float z1 = mvrt_u2f( bfi( bitMask( cm, 2 ), mvrt_f2u( tz1 ), mvrt_f2u( tzM ) ) );
-			const float u = fminf( fminf( x1, y1 ), z1 );					  // :365
-			const uint32_t mv = ( u == x1 ) ? 1u : ( ( u == y1 ) ? 2u : 4u ); // :366
-			const uint32_t childBit = cm ^ vMaskHi;							  // :369, child index + 24 (vMaskHi = vMask | 24)
-			const uint32_t childIndex = childBit & 7u;
-			const uint32_t nextMask = cm | mv;								  // :370
-			const bool leaf = node == MVRT_LEAF;							  // :322
-			const bool hasNext = ( cm & mv ) == 0;							  // :368
-			const bool exists = EMBED ? bitMask( node, childBit ) != 0u : ( ( nodeMask >> childIndex ) & 1u ) != 0;
-			const bool go = !leaf && exists && !( u < 0.0f ); // :373-375
-			const bool hit = leaf && ( 0.0f < S );			  // :324
-			const bool pop = leaf ? !hit : ( !go && !hasNext );
-			// advance within the node (:396-411): only the child mask changes
-			childMask = leaf ? childMask : ( ( !go && hasNext ) ? nextMask : cm );
-
-			if( go )
-			{
-				if( hasNext ) // push (:377-380)
-				{
-					const uint32_t slot = level & ( MVRT_RING - 1 );
-					const uint32_t clash = inLds & ( MVRT_RING_CLASH << slot );
-					if( clash ) // the slot still holds a shallower pending entry: evict it to HBM
-					{
-						const uint32_t lc = __builtin_ctz( clash );
-						*(u4v*)( (char*)spill + ( ( lc << spillShift ) + spillOff ) ) = myRing[slot * 64];
-						if( !EMBED ) *(uint32_t*)( (char*)spillMask + ( ( lc << spillMaskShift ) + spillMaskOff ) ) = myRingMask[slot * 64];
-						if( TREE ) *(uint32_t*)( (char*)spillMask2 + ( ( lc << spillMaskShift ) + spillMaskOff ) ) = myRingMask2[slot * 64];
-						inLds &= ~clash;
-					}
-					u4v e;
-					e.x = node;
-					// sign bits of a saved node's exit times are clear (entered with min >= 0; +0 - x and 0.5*(a+b) never
-					// yield -0.0 from non-negative-zero inputs), so the child mask can be OR-ed in without masking
-					e.y = lshlOr( nextMask, 31u, mvrt_f2u( tx1 ) );
-					e.z = bfi( 0x7FFFFFFFu, mvrt_f2u( ty1 ), nextMask << 30 );
-					e.w = bfi( 0x7FFFFFFFu, mvrt_f2u( tz1 ), nextMask << 29 );
-					myRing[slot * 64] = e;
-					if( !EMBED ) myRingMask[slot * 64] = ( TREE && ( ( s.levelsM1 - level ) & 1u ) ) ? bLo : nodeMask;
-					if( TREE ) myRingMask2[slot * 64] = bHi;
-					pending |= 1u << level;
-					inLds |= 1u << level;
-				}
-				if( EMBED )
-				{
-					// :381 -- 32-bit byte offset from the uniform node base (global_load with an SGPR base, no 64-bit VALU adds)
-					node = *(const uint32_t*)( (const char*)kids + ( ( ( node & 0xFFFFFFu ) << 5 ) | ( childIndex << 2 ) ) );
-				}
-				else if( TREE )
-				{
-					treeDescend( nodes, s.levelsM1, level, childIndex, &node, &nodeMask, &bLo, &bHi, &path );
-				}
-				else
-				{
-					const Node64* nd = nodes + node; // up to 2^32 nodes: 64-bit addressing
-					nodeMask = ( nd->psum[childIndex >> 2] >> ( 8u * ( childIndex & 3u ) ) ) & 0xFFu; // the child's mask: same line as
-					node = nd->children[childIndex];												 // its pointer
-				}
-				descents++;
-				if( !TREE ) path = ( path << 3 ) | childIndex;
-				tx1 = x1; // :382-386
-				ty1 = y1;
-				tz1 = z1;
-				level++;
-				childMask = 8u;
-			}
-			if( pop ) // :414-422
-			{
-				if( pending == 0 ) // miss
-				{
-					st = 2u;
-				}
-				else
-				{
-					const uint32_t L = 31u - __builtin_clz( pending );
-					const uint32_t bit = 1u << L;
-					// speculative LDS read (valid iff inLds & bit).  Issued as asm so that it stays a ds_read: the optimiser
-					// otherwise merges it with the spill read below into one flat load behind an address select
-					u4v ev;
-					asm volatile( "ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"( ev ) : "v"( ringAddr + ( ( L & ( MVRT_RING - 1 ) ) << 10 ) ) : "memory" );
-					uint4 e = make_uint4( ev.x, ev.y, ev.z, ev.w );
-					uint32_t m2 = 0;
-					if( !EMBED ) nodeMask = myRingMask[( L & ( MVRT_RING - 1 ) ) * 64];
-					if( TREE ) m2 = myRingMask2[( L & ( MVRT_RING - 1 ) ) * 64];
-					if( !( inLds & bit ) ) // rare; the empty asm keeps this a real branch (otherwise: address select + one flat load)
-					{
-						asm volatile( "" ::: "memory" );
-						e = *(const uint4*)( (const char*)spill + ( ( L << spillShift ) + spillOff ) );
-						if( !EMBED ) nodeMask = *(const uint32_t*)( (const char*)spillMask + ( ( L << spillMaskShift ) + spillMaskOff ) );
-						if( TREE ) m2 = *(const uint32_t*)( (const char*)spillMask2 + ( ( L << spillMaskShift ) + spillMaskOff ) );
-					}
-					if( TREE && ( ( s.levelsM1 - L ) & 1u ) )
-					{
-						bLo = nodeMask;
-						bHi = m2;
-						nodeMask = nonZeroBytes( bLo, bHi );
-					}
-					pending &= ~bit;
-					inLds &= ~bit;
-					if( !TREE ) path >>= 3u * ( level - L );
-					level = L;
-					node = e.x;
-					childMask = andOr( e.w >> 29, 4u, andOr( e.z >> 30, 2u, e.y >> 31 ) );
-					tx1 = mvrt_u2f( e.y & 0x7FFFFFFFu );
-					ty1 = mvrt_u2f( e.z & 0x7FFFFFFFu );
-					tz1 = mvrt_u2f( e.w & 0x7FFFFFFFu );
-				}
-			}
-			if( hit ) // :324-334 (t and nMajor: finishedHit)
-			{
-				st = 3u;
-			}
-		}
-		const int nDone = __builtin_popcountll( __ballot( st != 1u ) );
-		if( nDone == 64 || ( nDone >= MVRT_REFILL_MIN && !exhausted ) ) break;
-		}
-#else
 		// ---------------- (2) traversal steps until enough lanes are idle again ----------------
 		// NODE-VISIT step.  The reference examines the candidate children of a node one at a time (voxCommon.hpp:362-412); measured on
 		// a path-traced bunny that is 30.3 candidate tests per ray for 20.6 node visits and 14.7 descents, and 2.0 of the 5.5 pops lead
@@ -807,11 +760,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			const lmask v0 = mFirst & e0 & ~b0, v1 = n1 & e1 & ~b1, v2 = n2 & e2 & ~b2, v3 = n3 & e3;
 			const lmask mGo = inner & ( v0 | v1 | v2 | v3 );
 			const lmask l3 = v3, l2 = v2 | l3, l1 = v1 | l2; // a valid candidate at or after 3 / 2 / 1
-#ifndef MVRT_REFERENCE_PUSH
-			const lmask mPush = inner & ( ( v0 & l1 ) | ( ~v0 & ( ( v1 & l2 ) | ( ~v1 & v2 & l3 ) ) ) ); // only if a later VALID candidate exists
-#else
-			const lmask mPush = inner & ( ( v0 & n1 ) | ( ~v0 & ( ( v1 & n2 ) | ( ~v1 & v2 & n3 ) ) ) ); // A/B: the reference's rule (any later candidate)
-#endif
+			const lmask mPush = inner & ( ( v0 & l1 ) | ( ~v0 & ( ( v1 & l2 ) | ( ~v1 & v2 & l3 ) ) ) ); // only if a later VALID candidate exists (the reference: any later candidate; measured +8.6 %)
 			const lmask mHit = mLeaf & __ballot( 0.0f < S ); // :324
 			const lmask mPop = act & ~mHit & ~mGo;
 			// the entered candidate = the first valid one
@@ -854,6 +803,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 					if( !TREE ) path >>= 3u * ( level - L );
 					level = L;
 					node = popped.x;
+
 					if( !EMBED ) nodeMask = poppedMask;
 					tx1 = mvrt_u2f( popped.y & 0x7FFFFFFFu );
 					ty1 = mvrt_u2f( popped.z & 0x7FFFFFFFu );
@@ -927,6 +877,5 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 		}
 		st = LANE( hitM ) ? 3u : ( LANE( missM ) ? 2u : st );
 		childMask = LANE( mFirst ) ? 8u : ( ( LANE( cmX ) ? 1u : 0u ) | ( LANE( cmY ) ? 2u : 0u ) | ( LANE( cmZ ) ? 4u : 0u ) );
-#endif
 	}
 }

@@ -87,6 +87,51 @@ def test_trace_batch_bit_exact(mv, O, bunny256):
     assert (want["t"] != O.MAX_FLOAT).sum() > 10000
 
 
+def secondary_like_rays(sc, prim_ro, prim_rd, hits, seed):
+    """rays that start ON the voxels other rays hit (what the path tracer's shadow / bounce rays are): origin = ro + rd * t as the shade kernel
+    computes it, direction random; the hint = Morton code of the hit voxel"""
+    rng = np.random.default_rng(seed)
+    hit = hits["t"] != np.float32(3.402823466e38)
+    t = hits["t"][hit].astype(np.float32)
+    ro = (prim_ro[hit] + prim_rd[hit] * t[:, None]).astype(np.float32)
+    rd = rng.normal(size=ro.shape).astype(np.float32)
+    hint = sc.morton[hits["vIndex"][hit]].astype(np.uint64)
+    return ro, rd, hint
+
+
+@pytest.mark.parametrize("res", [256, 1024])
+def test_start_below_the_root_gives_the_results_of_the_walk_from_the_root(mv, O, bunny256, res):
+    """mvrt_trace_batch_hinted: every output -- descents included -- equals the oracle's (which starts at the root like the reference) for ANY
+    valid hint: the voxel the ray starts on (what the path tracer passes), a voxel somewhere else entirely, no hint; 256^3: the prefix tables reach
+    the hint's last level; 1024^3: two levels below them come from the children array"""
+    sc = bunny256 if res == 256 else O.build_scene_from_triangles(bunny_tris(), res)
+    svo = upload(mv, sc)
+    ro0, rd0 = random_rays(sc, 120_000, 21)
+    prim = svo.intersect(ro0, rd0, want_descents=True)
+    ro, rd, hint = secondary_like_rays(sc, ro0, rd0, prim, 22)
+    assert len(ro) > 5000
+    rng = np.random.default_rng(23)
+    sh = (rng.random(len(ro)) < 0.4).astype(np.uint8)
+    want = sc.trace(ro, rd, sh, threads=8, want_descents=True)
+    assert_hits_equal(want, svo.intersect_hinted(ro, rd, hint, sh))          # the voxel the ray starts on
+    wild = sc.morton[rng.integers(0, len(sc.morton), len(ro))].astype(np.uint64)
+    assert_hits_equal(want, svo.intersect_hinted(ro, rd, wild, sh))          # any voxel that exists
+    mixed = np.where(rng.random(len(ro)) < 0.5, hint, np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert_hits_equal(want, svo.intersect_hinted(ro, rd, mixed, sh))         # half of the rays unhinted
+    # rays from outside / inside / axis-parallel (the irregular path) with hints they have nothing to do with
+    wild0 = sc.morton[rng.integers(0, len(sc.morton), len(ro0))].astype(np.uint64)
+    assert_hits_equal(sc.trace(ro0, rd0, None, threads=8, want_descents=True), svo.intersect_hinted(ro0, rd0, wild0))
+    # the hinted walk really skips levels: with the right hint most secondary rays start at least 5 levels down -- visible in nothing but time,
+    # so only sanity-check the premise here: the hint's voxel contains (or touches) the origin
+    lo, _ = sc.bounds()
+    cell = np.floor((ro - lo) / np.float32(sc.dps)).astype(np.int64)
+    hx = np.zeros((len(hint), 3), np.int64)
+    for b in range(21):
+        for a in range(3):
+            hx[:, a] |= ((hint >> np.uint64(3 * b + a)) & np.uint64(1)).astype(np.int64) << b
+    assert (np.abs(cell - hx).max(1) <= 1).mean() > 0.99
+
+
 def test_trace_empty_and_ragged_batches(mv, O, bunny256):
     svo = upload(mv, bunny256)
     assert len(svo.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))["t"]) == 0
