@@ -15,6 +15,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -118,8 +120,15 @@ int main( int argc, char** argv )
 	std::vector<Device> dev( nDev );
 	uint64_t owned = 0;
 	const auto t0 = std::chrono::steady_clock::now();
-	for( int d = 0; d < nDev; d++ )
-	{
+	// one host thread per device: the replicated scene is built on all devices at once (N x setup in the time of one), and later every
+	// device's frame is submitted by its own thread (a frame is ~120 asynchronous launches per device: serial submission would cost the
+	// last device several milliseconds of a 10 ms frame)
+	auto onEveryDevice = [&]( const std::function<void( int )>& body ) {
+		std::vector<std::thread> th;
+		for( int d = 0; d < nDev; d++ ) th.emplace_back( body, d );
+		for( std::thread& t : th ) t.join();
+	};
+	onEveryDevice( [&]( int d ) {
 		Device& D = dev[d];
 		D.id = d;
 		D.comm = comms[d];
@@ -131,11 +140,12 @@ int main( int argc, char** argv )
 		D.pt->resizeFrameBufferIfNeeded( D.stream, W, H );
 		D.pt->loadHDRI( D.stream, hdrPath, hdrPath );
 		D.pt->updateScene( vertices, vcolors, vemissions, D.stream, lo, dps, gridRes );
-		owned = mvrt_pt_owned_pixels( D.pt->handle() );
-		mvrt::check( mvrt_malloc( (void**)&D.gathered, (uint64_t)nDev * owned * 16 ), "mvrt_malloc" );
+		const uint64_t own = mvrt_pt_owned_pixels( D.pt->handle() ); // (the same on every device: padded to equal shares)
+		mvrt::check( mvrt_malloc( (void**)&D.gathered, (uint64_t)nDev * own * 16 ), "mvrt_malloc" );
 		mvrt::check( mvrt_malloc( (void**)&D.frame, (uint64_t)W * H * 16 ), "mvrt_malloc" );
 		mvrt::check( mvrt_malloc( (void**)&D.frameU8, (uint64_t)W * H * 4 ), "mvrt_malloc" );
-	}
+	} );
+	owned = mvrt_pt_owned_pixels( dev[0].pt->handle() );
 	const double setupS = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
 
 	const float centre[3] = { lo.x + 0.5f * boxWide, lo.y + 0.5f * boxWide, lo.z + 0.5f * boxWide };
@@ -160,27 +170,23 @@ int main( int argc, char** argv )
 	for( int frame = 0; frame < frames; frame++ )
 	{
 		const auto f0 = std::chrono::steady_clock::now();
-		for( Device& D : dev )
-		{
+		onEveryDevice( [&]( int d ) {
+			Device& D = dev[d];
 			mvrt::check( mvrt_set_device( D.id ), "mvrt_set_device" );
 			D.pt->clearFrameBuffer( D.stream );
 			for( int k = 0; k < steps; k++ ) D.pt->step( D.stream, view, proj, focus, lensR );
 			mvrt::check( mvrt_pt_join( D.pt->handle(), D.stream ), "mvrt_pt_join" ); // launches the deferred steps; D.stream waits for them
-		}
+		} );
 		NCCL_CHECK( ncclGroupStart() );
 		for( Device& D : dev )
 			NCCL_CHECK( ncclAllGather( mvrt_pt_framebuffer_dev( D.pt->handle() ), D.gathered, owned * 4, ncclFloat, D.comm, (hipStream_t)D.stream ) );
 		NCCL_CHECK( ncclGroupEnd() );
-		for( Device& D : dev )
-		{
+		onEveryDevice( [&]( int d ) {
+			Device& D = dev[d];
 			mvrt::check( mvrt_set_device( D.id ), "mvrt_set_device" );
 			mvrt::check( mvrt_pt_assemble_tiles( D.gathered, nDev, owned, W, H, D.frame, D.stream ), "mvrt_pt_assemble_tiles" );
-		}
-		for( Device& D : dev )
-		{
-			mvrt::check( mvrt_set_device( D.id ), "mvrt_set_device" );
 			mvrt::check( mvrt_stream_synchronize( D.stream ), "sync" );
-		}
+		} );
 		const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - f0 ).count();
 		if( ms < bestMs ) bestMs = ms;
 		std::printf( "[frame %d] %d GPU(s), %dx%d, %d spp: %.3f ms\n", frame, nDev, W, H, steps * 16, ms );
@@ -205,6 +211,18 @@ int main( int argc, char** argv )
 		}
 	}
 	std::printf( "devices %d, voxels %llu, setup %.2f s, best frame %.3f ms\n", nDev, (unsigned long long)dev[0].pt->getNumberOfVoxels(), setupS, bestMs );
+	// rays of ONE frame, over all devices (intersect() calls: the same count the reference's megakernel would make)
+	unsigned long long rays = 0;
+	for( Device& D : dev )
+	{
+		mvrt::check( mvrt_set_device( D.id ), "mvrt_set_device" );
+		mvrt_pt_stats st;
+		mvrt::check( mvrt_pt_get_stats( D.pt->handle(), D.stream, &st ), "mvrt_pt_get_stats" );
+		rays += st.rays / (unsigned long long)frames;
+	}
+	std::printf( "{\"app\": \"tile_render\", \"n_gpus\": %d, \"width\": %d, \"height\": %d, \"spp\": %d, \"grid_res\": %d, \"frames\": %d, \"best_frame_ms\": %.3f, \"rays_per_frame\": %llu, "
+				 "\"mrays_per_s\": %.1f, \"setup_s\": %.2f, \"collective\": \"ncclAllGather of %llu float4 per device + assemble, inside the timed frame\"}\n",
+				 nDev, W, H, steps * 16, gridRes, frames, bestMs, rays, (double)rays / bestMs / 1e3, setupS, (unsigned long long)owned );
 
 	for( Device& D : dev )
 	{

@@ -113,6 +113,38 @@ def stress_traffic(n_rays):
     return int(json.load(open(p))["traffic_bytes_per_ray"] * n_rays)
 
 
+def cpu_primary(args):
+    """BASELINE.json configs[0]: scenes/bunny.obj voxelized at 256^3, primary rays through the pixel centres on the CPU -- what voxRT.cpp:307-358 times
+    (per-row CameraPinhole::shoot -> IntersectorOctree::intersect; serial, or ParallelFor over rows).  No GPU: the CPU oracle (oracle/, the port of
+    that loop) IS the thing measured here, as BASELINE.md section 3 asks -- 1 thread (the reference's default, and what BASELINE.md section 2 measured
+    on the survey container: 11.0 Mrays/s) and every core of this job."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import bunny_tris, probe_camera
+    from oracle import oracle as O
+    res = args.grid_res or 256
+    sc = O.build_scene_from_triangles(bunny_tris(), res)
+    cam = probe_camera(sc.origin, sc.dps, res)
+    W, H = args.width, args.height
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), args.cpu_threads)
+    out = {}
+    for label, th in (("1", 1), ("all", cores)):
+        sc.render_primary(cam, W, H, threads=th)  # warm-up (page in the octree)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = sc.render_primary(cam, W, H, threads=th)
+        out[label] = W * H * args.steps / (time.perf_counter() - t0) / 1e6
+    hits = int((r["t"] != O.MAX_FLOAT).sum())
+    print(json.dumps({
+        "metric": "Mrays/sec (primary) at %dx%d, CPU IntersectorOctree path" % (W, H), "value": round(out["all"], 3), "unit": "Mrays/s", "n_gpus": 0, "steps": args.steps,
+        "warmup": 1, "ms_per_step": round(W * H / out["all"] / 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "bunny.obj (tests/golden/bunny_tris.f32)",
+        "config": {"workload": "bunny.obj %d^3 SVO (%d voxels, %d DAG nodes), primary rays through pixel centres, CPU oracle = port of voxRT.cpp:307-358 (plumbing, no GPU)" % (res, len(sc.morton), len(sc.nodes)),
+                   "hits": hits, "descents_per_ray": round(float(r["descents"].mean()), 2)},
+        "cpu_baseline": {"value": round(out["all"], 3), "value_1_thread": round(out["1"], 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                         "sample": "%d full frames per figure" % args.steps,
+                         "survey_container_1_thread": {256: 11.0, 1024: 8.9, 2048: 7.2}.get(res)},
+        "roofline": None}), flush=True)
+
+
 def self_launch_cmd(n, argv, port):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
             os.path.abspath(__file__)] + list(argv)
@@ -166,10 +198,13 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--voxels", type=float, default=1.05e9, help="stress mode: random voxels of the synthetic octree")
     ap.add_argument("--rays", type=float, default=1.6e7, help="stress mode: incoherent rays per step")
-    ap.add_argument("--mode", default="pt", choices=["pt", "primary", "stress"], help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2)")
+    ap.add_argument("--mode", default="pt", choices=["pt", "primary", "stress", "cpu-primary"],
+                    help="pt = wavefront path tracer (headline); primary = the render kernel of voxRTGPU (config 2); stress = config 5; cpu-primary = config 1 (CPU only)")
     ap.add_argument("--emulate-tiles", type=int, default=0, help="diagnostic: render only tile 0 of N on one GPU (predicts per-rank time of an N-GPU run)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
+    if args.mode == "cpu-primary":
+        return cpu_primary(args)
     if args.grid_res == 0:
         args.grid_res = {"dragon": 2048, "rtcamp": 4096, "cave": 2048}[args.scene] if args.mode != "stress" else 8192
 
@@ -387,12 +422,19 @@ def main():
         tc = time.perf_counter()
         _, _, cnt = sc.render_pt(Hh, cam, W, H, 0, math_mode=1, fb=fb_cpu, pixel_begin=p0, pixel_end=p1, threads=cores)
         cpu_s = time.perf_counter() - tc
+        # ... and the 1-thread figure (BASELINE.md section 3 / SURVEY.md 8d ask for it beside the all-cores one): 1 / (2 * cores) of the band's rows
+        rows1 = max(rows // (2 * cores), 1)
+        q0 = (y0 + (rows - rows1) // 2) * W
+        t1 = time.perf_counter()
+        _, _, cnt1 = sc.render_pt(Hh, cam, W, H, 0, math_mode=1, fb=np.zeros((W * H, 4), np.float32), pixel_begin=q0, pixel_end=q0 + rows1 * W, threads=1)
+        cpu1_s = time.perf_counter() - t1
         # the same band from the GPU frame buffer (iteration 0 only) must agree bit for bit
         pt.clearFrameBuffer(None)
         pt.step(None, cam)
         gpu_band = pt.read_framebuffer()[p0:p1]
         cpu = {
             "value": round(cnt["rays"] / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "value_1_thread": round(cnt1["rays"] / cpu1_s / 1e6, 3), "sample_1_thread": "%d rows in the middle of that band: %d rays in %.1f s" % (rows1, cnt1["rays"], cpu1_s),
             "sample": "rows %d-%d of the %dx%d frame, iteration 0 (16 spp): %d samples, %d rays in %.1f s" % (y0, y0 + rows - 1, W, H, cnt["samples"], cnt["rays"], cpu_s),
             "gpu_band_bit_exact": bool(np.array_equal(gpu_band, fb_cpu[p0:p1])),
         }

@@ -14,12 +14,27 @@
 // GetCameraMatrix produces in the reference (PathTracer.hpp:152-153), images are raw pointers.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "IntersectorOctreeGPU.hpp"
 
 namespace mvrt
 {
+// What the reference's callers touch of hipUtil.hpp:48-74 `Buffer` on the frame buffers (RTCamp.cpp:169 `pt.m_frameBufferU8->data()`): a NON-owning view of
+// a device buffer the library owns (it is re-pointed by resizeFrameBufferIfNeeded).
+class Buffer
+{
+public:
+	Buffer( void* ptr, int64_t bytes ) : m_bytes( bytes ), m_ptr( ptr ) {}
+	int64_t bytes() const { return m_bytes; }
+	char* data() { return (char*)m_ptr; }
+
+private:
+	int64_t m_bytes;
+	void* m_ptr;
+};
+
 struct PathTracer
 {
 	PathTracer() {}
@@ -43,6 +58,8 @@ struct PathTracer
 	}
 	void cleanUp() // :71-79
 	{
+		m_frameBufferU8.reset();
+		m_frameBufferF32.reset();
 		m_intersectorOctreeGPU.attach( nullptr );
 		if( m_handle ) mvrt_pt_destroy( m_handle );
 		m_handle = nullptr;
@@ -52,8 +69,17 @@ struct PathTracer
 		check( mvrt_pt_resize_framebuffer_if_needed( m_handle, stream, width, height ), "PathTracer::resizeFrameBufferIfNeeded" );
 		m_width = width;
 		m_height = height;
+		// :90-93 -- uchar4 / float4 per OWNED pixel (= every pixel unless setTile split the frame)
+		const int64_t owned = (int64_t)mvrt_pt_owned_pixels( m_handle );
+		m_frameBufferU8.reset( new Buffer( mvrt_pt_framebuffer_u8_dev( m_handle ), owned * 4 ) );
+		m_frameBufferF32.reset( new Buffer( mvrt_pt_framebuffer_dev( m_handle ), owned * 16 ) );
+		m_steps = mvrt_pt_get_steps( m_handle );
 	}
-	void clearFrameBuffer( void* stream ) { check( mvrt_pt_clear_framebuffer( m_handle, stream ), "PathTracer::clearFrameBuffer" ); } // :98-102
+	void clearFrameBuffer( void* stream ) // :98-102
+	{
+		check( mvrt_pt_clear_framebuffer( m_handle, stream ), "PathTracer::clearFrameBuffer" );
+		m_steps = 0;
+	}
 	void loadHDRI( void* stream, const char* file, const char* filePrimary = 0 )													 // :104-116
 	{
 		check( mvrt_pt_load_hdri_file( m_handle, stream, file, filePrimary ), "PathTracer::loadHDRI" );
@@ -70,6 +96,7 @@ struct PathTracer
 	void step( void* stream, const float view[16], const float proj[16], float focus, float lensR )
 	{
 		check( mvrt_pt_step_matrices( m_handle, stream, view, proj, focus, lensR ), "PathTracer::step" );
+		m_steps = mvrt_pt_get_steps( m_handle ); // :159 m_steps++
 	}
 
 	// multi-GPU extension (not in the reference): render only the 256-pixel blocks b with b % tileCount == tileIndex
@@ -78,8 +105,11 @@ struct PathTracer
 	mvrt_pt* handle() const { return m_handle; }
 
 	IntersectorOctreeGPU m_intersectorOctreeGPU; // reference member m_intersectorOctreeGPU (:18), a value as there; bound to the handle's octree by setup()
+	std::unique_ptr<Buffer> m_frameBufferU8;  // :23 (filled by resolve / toImageAsync); views, see Buffer above
+	std::unique_ptr<Buffer> m_frameBufferF32; // :24
 	int m_width = 0;
 	int m_height = 0;
+	int m_steps = 0; // :27
 
 private:
 	mvrt_pt* m_handle = nullptr;

@@ -248,7 +248,7 @@ static int buildTopTable( mvrt_svo* s, hipStream_t st )
 	if( launchBuildPrefixRefs( s->kids.as<uint32_t>(), ( s->info.numberOfNodes - 1 ) | ( (uint32_t)s->rootMask << 24 ), hintTabLevelsOf( s->info.levels ),
 							   s->kids.as<uint32_t>() + (uint64_t)s->info.numberOfNodes * 8, st ) )
 		return 1;
-	static const int envK = getenv( "MVRT_TOP_LEVELS" ) ? atoi( getenv( "MVRT_TOP_LEVELS" ) ) : 7;
+	static const int envK = (int)mvrtKnob( "MVRT_TOP_LEVELS", 7 );
 	uint32_t k = (uint32_t)( envK < 0 ? 0 : ( envK > 8 ? 8 : envK ) );
 	if( k > s->info.levels ) k = s->info.levels;
 	if( k == 0 ) return 0;
@@ -776,15 +776,12 @@ struct mvrt_pt
 		memset( &hdri, 0, sizeof( hdri ) );
 		hdri.scale = 1.75f; // renderCommon.hpp:480
 		for( Slot& sl : slots ) memset( &sl.buf, 0, sizeof( sl.buf ) );
-		const char* e = getenv( "MVRT_PIPELINE_DEPTH" );
-		if( e ) depth = atoi( e );
+		depth = (int)mvrtKnob( "MVRT_PIPELINE_DEPTH", depth );
 		if( depth < 1 ) depth = 1;
 		if( depth > 4 ) depth = 4;
 		depthWanted = depth;
-		const char* sp = getenv( "MVRT_SPLIT_SMALL" );
-		if( sp ) splitSmallPasses = atoi( sp ) != 0;
-		const char* b = getenv( "MVRT_BATCH_STEPS" );
-		if( b ) batch = atoi( b );
+		splitSmallPasses = mvrtKnob( "MVRT_SPLIT_SMALL", 1 ) != 0;
+		batch = (int)mvrtKnob( "MVRT_BATCH_STEPS", 0 );
 		if( batch < 0 ) batch = 0;
 		if( batch > MVRT_MAX_BATCH ) batch = MVRT_MAX_BATCH;
 	}
@@ -1186,7 +1183,7 @@ int mvrt_pt::flush( bool moreStepsFollow )
 	// of the wave slots, overlap one pass's tails and shading with the other's traversal.  Same per-sample results; the frame-buffer
 	// additions stay in step order through the event chain.
 	const uint64_t samples = ownedPixels * MVRT_SPP_PER_STEP * (uint64_t)n;
-	static const uint64_t splitMax = getenv( "MVRT_SPLIT_SMALL_MAX" ) ? strtoull( getenv( "MVRT_SPLIT_SMALL_MAX" ), nullptr, 10 ) : 40000000ull;
+	static const uint64_t splitMax = (uint64_t)mvrtKnob( "MVRT_SPLIT_SMALL_MAX", 40000000ll );
 	// ... but only when this pass would otherwise run ALONE: if the caller keeps stepping, or an earlier pass is still in flight, the
 	// passes already overlap each other and halving their grids only slows them (measured: 2.68 -> 2.99 ms per step at 16 steps)
 	const bool alone = !moreStepsFollow && ( !lastAccum || !pendingJoin || hipEventQuery( lastAccum ) == hipSuccess );
@@ -1196,7 +1193,7 @@ int mvrt_pt::flush( bool moreStepsFollow )
 	pendingCams.clear();
 	if( !split ) return launchPass( cams.data(), first, n, 1 );
 	// `ways` sibling passes (at most one per work-buffer slot and per step), each restricted to 1/ways of the wave slots
-	static const int envWays = getenv( "MVRT_SPLIT_WAYS" ) ? atoi( getenv( "MVRT_SPLIT_WAYS" ) ) : 2;
+	static const int envWays = (int)mvrtKnob( "MVRT_SPLIT_WAYS", 2 );
 	int ways = envWays < 2 ? 2 : envWays;
 	if( ways > depth ) ways = depth;
 	if( ways > n ) ways = n;
@@ -1407,7 +1404,8 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 		out->shadowDescents = s[3];
 		out->hits = s[4];
 		out->samples = s[5];
-		if( getenv( "MVRT_PRINT_UTIL" ) )
+#ifdef MVRT_UTIL_STATS
+		if( getenv( "MVRT_PRINT_UTIL" ) ) // (a diagnostic build's tallies: tools/build_variant.sh util -DMVRT_UTIL_STATS)
 		{
 			unsigned long long u[4];
 			MVRT_HIP( hipMemcpy( u, pt->buf.stats + 8, sizeof( u ), hipMemcpyDeviceToHost ) );
@@ -1420,6 +1418,7 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 			for( int k = 0; k <= MVRT_MAX_DEPTH; k++ )
 				fprintf( stderr, "[util] stage %d: longest wave %llu iterations, waves %llu, longest ray %llu iterations\n", k, w[k], w[16 + k], w[32 + k] );
 		}
+#endif
 	}
 	pt->prof.collect();
 	out->traceLaunches = pt->prof.traceLaunches;

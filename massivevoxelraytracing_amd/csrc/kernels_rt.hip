@@ -934,20 +934,20 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 			{
 				// a pass that shares the GPU with a sibling pass on another stream takes only 1/div of the wave slots, so that the two
 				// really run side by side (a full persistent grid would hold every slot until its own tail)
-				static const int envDiv = getenv( "MVRT_TRACE_GRID_DIV" ) ? atoi( getenv( "MVRT_TRACE_GRID_DIV" ) ) : 0;
+				static const int envDiv = (int)mvrtKnob( "MVRT_TRACE_GRID_DIV", 0 );
 				// ... for its BIG launches only (the first bounces; live counts are on the device, so the stage stands in for them): a small
 				// launch finishes sooner the more lanes it may use, and is gone before it can be in the sibling's way
-				static const int divMaxStage = getenv( "MVRT_TRACE_DIV_MAX_STAGE" ) ? atoi( getenv( "MVRT_TRACE_DIV_MAX_STAGE" ) ) : 99;
+				static const int divMaxStage = (int)mvrtKnob( "MVRT_TRACE_DIV_MAX_STAGE", 99 );
 				const int div = stage > divMaxStage ? 1 : ( envDiv > 0 ? envDiv : frame.traceGridDiv );
 				if( div > 1 && g > nCUs * STREAM_WAVES_PER_CU / div ) g = nCUs * STREAM_WAVES_PER_CU / div;
 				// small launches keep only total / (64 * 16) waves alive, at least 2048 (two per SIMD): measured with the 8-slot ring on a 1/8 tile
 				// share -6.5 % (dragon, rtcamp stand-in), full frame -1 %, closed scene unchanged (gpurun_out/sweep_small2.log)
-				static const uint32_t envRpl = getenv( "MVRT_SMALL_RPL" ) ? (uint32_t)atoi( getenv( "MVRT_SMALL_RPL" ) ) : 16u;
-				static const uint32_t envMinW = getenv( "MVRT_SMALL_MINW" ) ? (uint32_t)atoi( getenv( "MVRT_SMALL_MINW" ) ) : 2048u;
+				static const uint32_t envRpl = (uint32_t)mvrtKnob( "MVRT_SMALL_RPL", 16 );
+				static const uint32_t envMinW = (uint32_t)mvrtKnob( "MVRT_SMALL_MINW", 2048 );
 				smallRpl = envRpl;
 				smallMinW = envMinW;
 				// experiment knob: waves per CU of a full-grid traversal launch (32 = every slot the register budget allows and then some)
-				static const int wpc = getenv( "MVRT_TRACE_WAVES_PER_CU" ) ? atoi( getenv( "MVRT_TRACE_WAVES_PER_CU" ) ) : 0;
+				static const int wpc = (int)mvrtKnob( "MVRT_TRACE_WAVES_PER_CU", 0 );
 				if( wpc > 0 && g > nCUs * wpc / ( div > 1 ? div : 1 ) ) g = nCUs * wpc / ( div > 1 ? div : 1 );
 			}
 			if( svo.embedded )

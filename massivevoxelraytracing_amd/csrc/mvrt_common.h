@@ -218,4 +218,13 @@ void mvrtSetError( const char* fmt, ... );
 		}                                                                                             \
 	} while( 0 )
 
+// Experiment knobs: the product has none -- every tuning value is the constant its measurement settled (profiles/*_experiments.txt).  A build with
+// -DMVRT_EXPERIMENT (tools/build_variant.sh) reads the same values from the environment for A/B runs.
+#ifdef MVRT_EXPERIMENT
+#include <stdlib.h>
+static inline long long mvrtKnob( const char* name, long long settled ) { const char* e = getenv( name ); return e ? atoll( e ) : settled; }
+#else
+static inline long long mvrtKnob( const char*, long long settled ) { return settled; }
+#endif
+
 static inline uint32_t divUp( uint64_t a, uint64_t b ) { return (uint32_t)( ( a + b - 1 ) / b ); }

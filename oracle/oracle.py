@@ -255,6 +255,11 @@ class Scene:
         if fb is None:
             fb = np.zeros((W * H, 4), np.float32)
         pe = W * H if pixel_end < 0 else pixel_end
+        # the C side writes fb[pixel_begin:pe], 16 samples per pixel and one byte per sample without any check of its own (r02: a band that ran
+        # past the frame wrote past a caller's buffer and took the test process down)
+        assert 0 <= pixel_begin <= pe <= W * H, "render_pt: pixel range [%d, %d) outside the %dx%d frame" % (pixel_begin, pe, W, H)
+        assert fb.dtype == np.float32 and fb.flags.c_contiguous and fb.size >= W * H * 4, "render_pt: fb must be a contiguous float32 array of W*H*4"
+        assert cam.size == 15 and pmj.dtype == np.float32 and pmj.size == PMJ_FLOATS
         sl = np.zeros(((pe - pixel_begin) * 16, 3), np.float32) if want_samples else None
         cnt = np.zeros(6, np.uint64)
         if path_hits is not None:

@@ -33,6 +33,20 @@ int main( int argc, char** argv )
 	pt.toImageAsync( stream, image.data() );
 	mvrt::check( mvrt_stream_synchronize( stream ), "sync" );
 	std::printf( "steps %d voxels %llu octree bytes %llu\n", pt.getSteps(), (unsigned long long)pt.getNumberOfVoxels(), (unsigned long long)pt.getOctreeBytes() );
+	// RTCamp.cpp:160-169: resolve, then a device-to-device copy out of pt.m_frameBufferU8->data() into a pooled buffer
+	pt.resolve( stream );
+	void* pooled = nullptr;
+	mvrt::check( mvrt_malloc( &pooled, 64 * 36 * 4 ), "malloc" );
+	mvrt::check( mvrt_memcpy_d2d( pooled, pt.m_frameBufferU8->data(), 64 * 36 * 4, stream ), "d2d" );
+	std::vector<uint8_t> copy( 64 * 36 * 4 );
+	mvrt::check( mvrt_memcpy_d2h( copy.data(), pooled, copy.size(), stream ), "d2h" );
+	std::vector<float> f32( 64 * 36 * 4 );
+	mvrt::check( mvrt_memcpy_d2h( f32.data(), pt.m_frameBufferF32->data(), f32.size() * 4, stream ), "d2h" );
+	double w = 0;
+	for( size_t i = 3; i < f32.size(); i += 4 ) w += f32[i];
+	std::printf( "m_steps %d u8 bytes %lld f32 bytes %lld same %d sumW %.1f\n", pt.m_steps, (long long)pt.m_frameBufferU8->bytes(), (long long)pt.m_frameBufferF32->bytes(),
+				 (int)( copy == image ), w );
+	mvrt_free( pooled );
 
 	mvrt::IntersectorOctreeGPU isect; // voxRTGPU.cpp:104-171
 	isect.build( vertices, vcolors, vemissions, nullptr, stream, V3{ 0, 0, 0 }, 1.0f / 64, 64 );

@@ -203,3 +203,22 @@ def test_bench_self_launches_its_ranks():
     line = json.loads(out.strip().split("\n")[-1])
     assert line["n_gpus"] == 1 and line["n_ranks_seen"] == 1 and line["value"] > 0 and line["config"]["gather_ok"] is True
     assert "RCCL" in line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_frame_buffer_members(tmp_path):
+    """the reference's public members a caller reads (PathTracer.hpp:23-27): RTCamp.cpp:169 copies pt.m_frameBufferU8->data() device to device
+    after resolve(); m_steps counts step() calls.  tests/cpp/mirror_usage.cpp does exactly that on the header-only mirror."""
+    import shutil as sh
+    import massivevoxelraytracing_amd as mv
+    gxx = sh.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "mirror_usage"
+    libdir = os.path.dirname(mv.LIB_PATH)
+    subprocess.check_call([gxx, "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mirror_usage.cpp"), "-o", str(exe),
+                           "-L", libdir, "-l:libmvrt_hip.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    sh.copy(os.path.join(GOLDEN, "monks_forest_s.hdr"), tmp_path / "monks_forest_s.hdr")
+    out = subprocess.check_output([str(exe), "run"], cwd=tmp_path, timeout=300).decode()
+    assert "steps 1 " in out
+    assert "m_steps 1 u8 bytes %d f32 bytes %d same 1 sumW %.1f" % (64 * 36 * 4, 64 * 36 * 16, 64 * 36 * 16.0) in out
