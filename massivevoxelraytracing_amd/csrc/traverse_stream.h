@@ -495,7 +495,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 						// readfirstlane, not a shuffle: the cursor state (and with it `exhausted` and the exit test of the step loop) is then
 						// wave-uniform FOR THE COMPILER -- scalar registers, scalar branches, and the lane masks of the step loop stay in SGPRs
 						// across its exit instead of being copied to VGPRs in every iteration
-						base = (unsigned long long)__builtin_amdgcn_readfirstlane( (uint32_t)base ) | ( (unsigned long long)__builtin_amdgcn_readfirstlane( (uint32_t)( base >> 32 ) ) << 32 );
+						base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane( (uint32_t)base ) | ( (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane( (uint32_t)( base >> 32 ) ) << 32 );
 						if( base >= total )
 						{
 							exhausted = true;
