@@ -999,7 +999,15 @@ static int allocWorkInner( mvrt_pt* pt )
 			continue;
 		}
 		if( allocWorkSlot( pt, sl ) ) return 1;
-		if( pt->depth > 1 && !sl.stream ) MVRT_HIP( hipStreamCreateWithFlags( &sl.stream, hipStreamNonBlocking ) );
+		if( pt->depth > 1 && !sl.stream )
+		{
+			// (experiment knob: slot streams of different priorities live in different hardware-queue pools and are dispatched in priority order)
+			const int mode = (int)mvrtKnob( "MVRT_SLOT_PRIO", 0 );
+			int lo = 0, hi = 0;
+			MVRT_HIP( hipDeviceGetStreamPriorityRange( &lo, &hi ) );
+			const int prio = mode == 0 ? 0 : ( mode == 1 ? ( i == 0 ? hi : ( i == 2 ? lo : 0 ) ) : ( i % 2 == 0 ? hi : lo ) );
+			MVRT_HIP( hipStreamCreateWithPriority( &sl.stream, hipStreamNonBlocking, prio ) );
+		}
 		if( !sl.accumDone ) MVRT_HIP( hipEventCreateWithFlags( &sl.accumDone, hipEventDisableTiming ) );
 	}
 	pt->nextSlot = pt->lastSlot = 0;
@@ -1201,7 +1209,10 @@ int mvrt_pt::flush( bool moreStepsFollow )
 	for( int k = 0; k < ways; k++ )
 	{
 		const int cnt = ( n - done ) / ( ways - k );
-		if( launchPass( cams.data() + done, first + done, cnt, ways ) ) return 1;
+		// (r02: each sibling's traversal launches took 1 / ways of the wave slots; r03 re-measured with the cheaper-to-drain kernel: full grids are 1-2 %
+		//  better on a 1/8 share -- dragon 2.744 -> 2.698, rtcamp 2.421 -> 2.393 ms per step -- the dispatcher hands the slots of retiring waves to the sibling)
+		static const int siblingDiv = (int)mvrtKnob( "MVRT_SIBLING_GRID_DIV", 1 );
+		if( launchPass( cams.data() + done, first + done, cnt, siblingDiv > 0 ? siblingDiv : ways ) ) return 1;
 		done += cnt;
 	}
 	return 0;
