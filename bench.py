@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json): wavefront path tracing of a sparse voxel
 octree at 1920x1080, 64 spp (4 steps of 16 spp), reported as Mrays/s (primary + secondary rays).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid-res R] [--scene dragon|rtcamp|cave]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid-res R] [--scene dragon|rtcamp|cave|tunnel]
 
 N > 1 without a launcher (`python bench.py --gpus N`): bench.py starts its own ranks -- `python -m torch.distributed.run --nproc-per-node N
 bench.py ...` as a child process, before this process imports torch or the library -- and relays rank 0's line.  Under an explicit
@@ -184,8 +184,8 @@ def main():
     ap.add_argument("--build-flags", type=int, default=0, help="octree build flags (MVRT_BUILD_*); 0 = the reference's DAG with embedded masks")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid-res", type=int, default=0, help="0 = the scene's BASELINE size (dragon 2048, rtcamp 4096, cave 2048)")
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "rtcamp", "cave"])
+    ap.add_argument("--grid-res", type=int, default=0, help="0 = the scene's BASELINE size (dragon 2048, rtcamp 4096, cave 2048, tunnel 4096)")
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "rtcamp", "cave", "tunnel"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--detail", type=float, default=1.0)
@@ -206,7 +206,7 @@ def main():
     if args.mode == "cpu-primary":
         return cpu_primary(args)
     if args.grid_res == 0:
-        args.grid_res = {"dragon": 2048, "rtcamp": 4096, "cave": 2048}[args.scene] if args.mode != "stress" else 8192
+        args.grid_res = {"dragon": 2048, "rtcamp": 4096, "cave": 2048, "tunnel": 4096}[args.scene] if args.mode != "stress" else 8192
 
     force_dist = os.environ.get("MVRT_FORCE_DIST") == "1"
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist) and args.mode == "pt":
@@ -267,6 +267,8 @@ def main():
     centre = (lo + hi) / 2
     if args.scene == "cave":
         cam = scenes.cave_camera(lo, hi)
+    elif args.scene == "tunnel":
+        cam = scenes.tunnel_camera(lo, hi)
     else:
         eye = centre + (np.array([2.6, 1.5, 3.1]) if args.scene == "dragon" else np.array([4.2, 2.2, 5.0]))
         cam = scenes.look_at_camera(eye, centre, 40.0, float(np.linalg.norm(eye - centre)), 0.02)
@@ -441,7 +443,8 @@ def main():
 
     if rank == 0:
         spp = 16 * frame_steps
-        names = {"dragon": "xyzrgb_dragon stand-in", "rtcamp": "rtcamp9 stand-in", "cave": "closed cave (rtcamp9-class occlusion)"}
+        names = {"dragon": "xyzrgb_dragon stand-in", "rtcamp": "rtcamp9 stand-in", "cave": "closed cave (rtcamp9-class occlusion)",
+                 "tunnel": "closed tunnel (sized like the reference's slide-67 scene: 4096^3, ~41 M voxels)"}
         out = {
             "metric": "Mrays/sec (primary+secondary) at %dx%d, %d spp" % (W, H, spp),
             "value": round(rays / elapsed / 1e6, 2),

@@ -104,6 +104,9 @@ int mvrt_svo_build_synthetic( mvrt_svo* svo, int gridRes, uint64_t nRandomVoxels
 /* Adopt an SVO built elsewhere (e.g. IntersectorOctree::buildDAGReference on the CPU, IntersectorOctree.hpp:
  * 224-231): nodes in the reference's 68-byte layout, root last.  embeddedMask = 0 selects the variant where
  * the mask is fetched from the node (voxCommon.hpp:353-356; required above 0xFFFFFF nodes). */
+/* nVoxelsPSum is used as stored: vIndex = the sum of the stored values along the path (voxCommon.hpp:388-391), whatever they are -- e.g. all zero
+ * for buildOctreeNaive's nodes (IntersectorOctree.hpp:195), which then give vIndex 0 like the reference.  (Internally the last level's value is
+ * replaced by a popcount of the mask when the upload is found to carry exactly that there, as every octree built by bottomUpOctreeBuild does.) */
 int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_t numberOfNodes, const void* attribs8Host, uint32_t numberOfVoxels, const float origin[3],
 					 float dps, int gridRes, int hasEmission, int embeddedMask, void* stream );
 int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info );

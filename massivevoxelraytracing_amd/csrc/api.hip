@@ -151,6 +151,7 @@ struct mvrt_svo
 	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
 	mvrt_svo_info info;
 	uint8_t rootMask = 0;
+	uint32_t leafPsumIsPopcount = 1; // (uploads: checked, see launchCheckLeafPsum)
 	mvrt_pt* owner = nullptr; // the PathTracer this is the m_intersectorOctreeGPU of (its deferred / in-flight steps read this octree)
 	mvrt_svo()
 	{
@@ -224,6 +225,7 @@ struct mvrt_svo
 		d.topLevels = topLevels;
 		d.tree = tree;
 		d.treeRoot = treeRoot;
+		d.leafPsumIsPopcount = leafPsumIsPopcount;
 		return d;
 	}
 };
@@ -318,6 +320,17 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	svo->info.totalDumpedVoxels = 0;
 	setBounds( svo, origin, dps, gridRes );
 	svo->rootMask = ( (const uint8_t*)nodes68Host )[(uint64_t)( numberOfNodes - 1 ) * 68];
+	svo->leafPsumIsPopcount = 1;
+	if( embeddedMask ) // an uploaded octree may carry any nVoxelsPSum (mvrt.h): the popcount shortcut of the last level only for canonical ones
+	{
+		DevBuf bad;
+		if( bad.alloc( 4 ) ) return 1;
+		if( launchCheckLeafPsum( svo->nodes, svo->masks, numberOfNodes, bad.as<uint32_t>(), st ) ) return 1;
+		uint32_t h = 0;
+		MVRT_HIP( hipMemcpyAsync( &h, bad.p, 4, hipMemcpyDeviceToHost, st ) );
+		MVRT_HIP( hipStreamSynchronize( st ) );
+		svo->leafPsumIsPopcount = h ? 0u : 1u;
+	}
 	if( buildTopTable( svo, st ) ) return 1;
 	MVRT_HIP( hipStreamSynchronize( st ) );
 	return 0;
@@ -341,6 +354,7 @@ static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origi
 	svo->info.hasEmission = r.hasEmission;
 	svo->info.embeddedMask = r.embedded; // 0 when the octree has >= 0xFFFFFF nodes (IntersectorOctreeGPU.hpp:231) or on request
 	svo->info.totalDumpedVoxels = r.totalDumped;
+	svo->leafPsumIsPopcount = 1; // (this library's builder writes the exclusive popcounts)
 	setBounds( svo, origin, dps, gridRes );
 	MVRT_HIP( hipMemcpy( &svo->rootMask, svo->masks + ( r.nNodes - 1 ), 1, hipMemcpyDeviceToHost ) );
 	if( buildTopTable( svo, nullptr ) ) return 1;

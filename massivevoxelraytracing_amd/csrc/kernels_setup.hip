@@ -52,6 +52,32 @@ int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, ui
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
+// embedded flavour, uploaded octrees: is nVoxelsPSum of every PARENT OF VOXELS the exclusive popcount of its mask (what bottomUpOctreeBuild writes,
+// voxKernel.cu:296-329)?  voxelIndexFromPath replaces the last level's nVoxelsPSum fetch by that popcount only then; an octree uploaded with other
+// values there (e.g. buildOctreeNaive's zeros, IntersectorOctree.hpp:195) gets the stored values, as the reference's traversal would use them.
+__global__ void __launch_bounds__( 256 ) kCheckLeafPsum( const Node64* __restrict__ nodes, const uint8_t* __restrict__ masks, uint32_t nNodes, uint32_t* __restrict__ bad )
+{
+	for( uint32_t n = blockIdx.x * 256 + threadIdx.x; n < nNodes; n += gridDim.x * 256 )
+	{
+		const uint32_t mask = masks[n];
+		uint32_t run = 0;
+		bool wrong = false;
+		for( uint32_t c = 0; c < 8; c++ )
+		{
+			if( !( ( mask >> c ) & 1u ) ) continue;
+			if( nodes[n].children[c] == MVRT_LEAF && nodes[n].psum[c] != run ) wrong = true;
+			run++;
+		}
+		if( wrong ) atomicOr( bad, 1u );
+	}
+}
+int launchCheckLeafPsum( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint32_t* badDev, hipStream_t stream )
+{
+	MVRT_HIP( hipMemsetAsync( badDev, 0, 4, stream ) );
+	hipLaunchKernelGGL( kCheckLeafPsum, dim3( cappedGrid( nNodes ) ), dim3( 256 ), 0, stream, nodes, masks, nNodes, badDev );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
 int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, uint64_t nNodes, hipStream_t stream )
 {
 	if( nNodes == 0 ) return 0;

@@ -89,6 +89,7 @@ int launchAssembleTiles( const float4* gathered, int tileCount, uint64_t rankStr
 // nonEmbedded != 0: psum goes to psumCold (nNodes * 8 u32) and the 8 child masks into Node64::psum[0..1]
 int launchConvertNodes( const uint8_t* nodes68, uint32_t nNodes, Node64* out, uint8_t* masks, uint32_t* psumCold, int nonEmbedded, hipStream_t stream );
 int launchNodesTo68( const Node64* nodes, const uint8_t* masks, const uint32_t* psumCold, uint32_t nNodes, uint8_t* nodes68, int nonEmbedded, hipStream_t stream );
+int launchCheckLeafPsum( const Node64* nodes, const uint8_t* masks, uint32_t nNodes, uint32_t* badDev, hipStream_t stream ); // embedded flavour, after an upload
 int launchSplitPsum( Node64* nodes, const uint8_t* masks, uint32_t* psumCold, uint64_t nNodes, hipStream_t stream ); // in place, after a build
 // tree flavour -> the reference's 68-byte nodes (mask, children[8], nVoxelsPSum[8]) from { mask, first child } per node
 int launchTreeTo68( const uint8_t* masks, const uint32_t* first, const uint32_t* levelBase, const uint32_t* levelCount, int levels, uint32_t nNodes, uint32_t nVoxels, uint8_t* nodes68,

@@ -179,6 +179,7 @@ struct SvoDev
 	// tree flavour (svo_build.hip): `nodes` are two-level bricks, treeRoot is where the traversal starts (a brick index, or a voxel index for a
 	// one-level octree); hits report the voxel index directly
 	uint32_t tree, treeRoot;
+	uint32_t leafPsumIsPopcount; // embedded flavour: nVoxelsPSum of the parents of voxels = exclusive popcount of their mask (every octree this library builds; checked for uploads)
 };
 
 MVRT_DI f3 getHitN( int major, f3 rd ) // voxCommon.hpp:564-577

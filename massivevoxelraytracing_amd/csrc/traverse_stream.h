@@ -120,7 +120,7 @@ MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 		const Node64* nd = s.nodes + n;
 		if( s.embedded )
 		{
-			if( l + 1u == s.levels && l > l0 )
+			if( l + 1u == s.levels && l > l0 && s.leafPsumIsPopcount )
 			{
 				// the parent of the voxel: its children are voxels, one each, so its nVoxelsPSum[c] is the number of its children before c --
 				// a popcount of the mask that came with the reference to it: no fetch for the last level

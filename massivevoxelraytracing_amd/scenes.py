@@ -219,7 +219,47 @@ def cave_camera(lower, upper):
     return look_at_camera(eye, tgt, 60.0, float(np.linalg.norm(tgt - eye)), 0.01)
 
 
-SCENES = {"dragon": dragon_standin, "rtcamp": rtcamp_standin, "cave": cave_standin}
+def tunnel_standin(detail=1.0):
+    """A CLOSED scene sized like the reference's published path-tracing figure (seminar slide 67: 'RT Camp scene', 4096^3, 41 M voxels): a bumpy
+    tunnel of 8 x 3.4 x 3.4 units -- its length spans the grid, its cross-section 0.42 of it, which puts ~41 M surface voxels into a 4096^3 grid
+    (a room that fills the grid would have ~150 M) -- with boulders along the floor, emissive lamps under the ceiling and a window in the far end wall
+    through which the HDRI reaches.  Camera inside: `tunnel_camera()`; nearly every bounce hits."""
+    n = max(int(1536 * detail), 24)
+    m = max(int(448 * detail), 12)
+    X, Y, Z = 4.0, 1.7, 1.7
+    parts = [
+        _panel((-X, -Y, -Z), (2 * X, 0, 0), (0, 0, 2 * Z), (0, 1, 0), n, m, 0.07, 5),     # floor
+        _panel((-X, Y, -Z), (2 * X, 0, 0), (0, 0, 2 * Z), (0, -1, 0), n, m, 0.06, 6),     # ceiling
+        _panel((-X, -Y, -Z), (2 * X, 0, 0), (0, 2 * Y, 0), (0, 0, 1), n, m, 0.05, 8),     # side walls
+        _panel((-X, -Y, Z), (2 * X, 0, 0), (0, 2 * Y, 0), (0, 0, -1), n, m, 0.05, 9),
+        _panel((-X, -Y, -Z), (0, 0, 2 * Z), (0, 2 * Y, 0), (1, 0, 0), m, m, 0.04, 7),     # near end wall
+        _panel((X, -Y, -Z), (0, 0, 2 * Z), (0, 2 * Y, 0), (-1, 0, 0), m, m, 0.04, 10, hole=(0.35, 0.65, 0.40, 0.75)),  # far end wall with a window
+    ]
+    for i in range(9):  # boulders along the floor, alternating sides
+        cx = -3.3 + 0.82 * i
+        cz = (0.9 if i % 2 else -0.9) + 0.12 * _fsin(2.1 * i)
+        rad = 0.26 + 0.07 * (0.5 + 0.5 * _fcos(1.3 * i))
+        parts.append(uv_sphere((cx, -Y + rad * 0.85, cz), rad, max(int(224 * detail), 12), max(int(112 * detail), 8), bump=0.09))
+    geo = np.concatenate(parts, axis=0)
+    ems = np.concatenate([box((x, Y - 0.14, -0.12), (x + 0.5, Y - 0.11, 0.12)) for x in (-3.4, -2.0, -0.6, 0.8, 2.2)], axis=0)
+    tris = np.concatenate([geo, ems], axis=0)
+    em = np.zeros(len(tris), bool)
+    em[len(geo):] = True
+    cols, emis = _colorize(tris, em, emission=(1.0, 0.92, 0.8))
+    return tris.reshape(-1, 3), cols, emis
+
+
+def tunnel_camera(lower, upper):
+    """camera inside the tunnel of tunnel_standin: near the closed end, at mid height, looking down its length.  (The grid is a cube over the scene's
+    LONGEST extent with its origin at the bounding box's minimum: the tunnel lies along the grid's lower y / z edge, not around its centre.)"""
+    lo, hi = np.asarray(lower, np.float64), np.asarray(upper, np.float64)
+    ext = (hi - lo).max()
+    eye = lo + np.array([0.09, 0.21, 0.215]) * ext
+    tgt = lo + np.array([0.80, 0.19, 0.205]) * ext
+    return look_at_camera(eye, tgt, 55.0, float(np.linalg.norm(tgt - eye)) * 0.5, 0.01)
+
+
+SCENES = {"dragon": dragon_standin, "rtcamp": rtcamp_standin, "cave": cave_standin, "tunnel": tunnel_standin}
 
 
 def bounding_grid(vertices, grid_res):

@@ -63,6 +63,8 @@ def bench_camera(scenes, info, name):
     centre = (lo + hi) / 2
     if name == "cave":
         return scenes.cave_camera(lo, hi)
+    if name == "tunnel":
+        return scenes.tunnel_camera(lo, hi)
     eye = centre + (np.array([2.6, 1.5, 3.1]) if name == "dragon" else np.array([4.2, 2.2, 5.0]))
     return scenes.look_at_camera(eye, centre, 40.0, float(np.linalg.norm(eye - centre)), 0.02)
 
@@ -302,3 +304,36 @@ def test_closed_scene_cave_1024(mv, O, hdr):
         band = tasks[(tasks >= p0 * 16) & (tasks < (p0 + n) * 16)] - p0 * 16
         assert np.array_equal(band, np.nonzero(hits > s)[0]), s
     assert live[7] > 0.5 * W * H * 16  # most paths are still alive going into the last bounce: buffers sized for the bound are really used
+
+
+def test_closed_scene_tunnel_4096_the_size_of_the_reference_figure(mv, O, hdr):
+    """the closed scene that is sized like the reference's published path-tracing figure (seminar slide 67: RT Camp scene, 4096^3, 41 M voxels,
+    12.5 ms per sample on an RX 7900 XTX): ~38 M voxels at 4096^3, camera inside, >= 15 rays per sample.  GPU builder == oracle builder at this
+    size, full-HD step: properties + a 16 384-pixel oracle band bit for bit + stable compaction in every stage."""
+    from massivevoxelraytracing_amd import scenes
+    (v, c, e, origin, dps), sc = scene_and_oracle(O, "tunnel", 4096)
+    rgba, hw, hh = hdr
+    pt = make_pt(mv, hdr)
+    pt.updateScene(v, c, e, None, origin, dps, 4096)
+    info = pt.m_intersectorOctreeGPU.info()
+    assert 36_000_000 < info.numberOfVoxels < 42_000_000 and info.embeddedMask == 1
+    assert_same_octree(O, pt.m_intersectorOctreeGPU, sc)
+    cam = bench_camera(scenes, info, "tunnel")
+    pt.set_debug_capture(True)
+    pt.set_batch_steps(1)
+    pt.step(None, cam)
+    fb = pt.read_framebuffer()
+    st = pt.stats()
+    frame_properties(fb, st, W * H)
+    assert st["rays"] >= 15 * st["samples"]
+    n = 16384
+    p0 = (H // 2) * W
+    hits = np.zeros(n * 16, np.uint8)
+    ref = np.zeros((W * H, 4), np.float32)
+    _, _, cnt = sc.render_pt(O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1), cam, W, H, 0, math_mode=1, fb=ref, pixel_begin=p0, pixel_end=p0 + n, threads=THREADS, path_hits=hits)
+    assert np.array_equal(fb[p0:p0 + n], ref[p0:p0 + n])
+    for s in range(8):
+        tasks = pt.debug_stage_survivors(s, W * H * 16)
+        assert (np.diff(tasks.astype(np.int64)) > 0).all(), s
+        band = tasks[(tasks >= p0 * 16) & (tasks < (p0 + n) * 16)] - p0 * 16
+        assert np.array_equal(band, np.nonzero(hits > s)[0]), s

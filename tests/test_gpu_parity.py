@@ -152,6 +152,27 @@ def test_trace_non_embedded_variant(mv, O, bunny256):
     assert_hits_equal(want, svo.intersect(ro, rd, want_descents=True))
 
 
+def test_uploaded_octree_with_non_canonical_psum_gives_the_stored_sums(mv, O, bunny256):
+    """an uploaded octree may carry any nVoxelsPSum -- buildOctreeNaive leaves them zero (IntersectorOctree.hpp:195) and the reference's
+    traversal then reports vIndex 0.  The library must sum what is STORED (no popcount shortcut on the last level) for such nodes."""
+    nodes = bunny256.nodes.copy()
+    nodes["psum"][:] = 0
+    sc = O.Scene(nodes, bunny256.attrs, bunny256.origin, bunny256.dps, 256)
+    svo = upload(mv, sc)
+    ro, rd = random_rays(bunny256, 30_000, 31)
+    want = sc.trace(ro, rd, threads=8, want_descents=True)
+    got = svo.intersect(ro, rd, want_descents=True)
+    assert_hits_equal(want, got)
+    assert (got["vIndex"] == 0).all() and (want["t"] != O.MAX_FLOAT).sum() > 1000
+    # ... and arbitrary values: a constant 3 per child gives 3 * levels
+    nodes["psum"][:] = 3
+    sc3 = O.Scene(nodes, bunny256.attrs, bunny256.origin, bunny256.dps, 256)
+    got3 = upload(mv, sc3).intersect(ro, rd)
+    hit = got3["t"] != O.MAX_FLOAT
+    assert (got3["vIndex"][hit] == 24).all()
+    assert_hits_equal(sc3.trace(ro, rd, threads=8), got3)
+
+
 def test_render_primary_golden_and_oracle(mv, O, bunny256):
     svo = upload(mv, bunny256)
     cam = probe_camera(bunny256.origin, bunny256.dps, 256)

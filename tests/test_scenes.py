@@ -15,6 +15,8 @@ PINS = {
     ("rtcamp", 0.25): (366056, "e7abec97fff2c6d34f79d60bbe4abcd6d186a6c51ed67bca5ace56e49df5c6f6"),
     ("cave", 1.0): (3174934, "9b86c0b1f4792a8f8853aeb5342b3dce44e78cb81c8c07686d215b86a786b2b1"),
     ("cave", 0.25): (193116, "818054457b6c0a8a4e103ec0ae680df3cbe5687a2577b96c79e42380be4c48a8"),
+    ("tunnel", 1.0): (6691890, "237193df5dc1a3027e74531700268d06f07fe1b1bf4977fd7f1fa9fe87d4e29d"),
+    ("tunnel", 0.25): (413604, "33d5774b825d0f6c676c1468a94d71b3495fd50388827f4a932f59d81e8a357a"),
 }
 
 
