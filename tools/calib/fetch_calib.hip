@@ -17,6 +17,18 @@ __global__ void kStream( const float4* __restrict__ p, uint64_t n, float* out )
 	}
 	if( acc == 12345.678f ) out[0] = acc;
 }
+// the path tracer's shade / generate kernels: one dword per lane, consecutive lanes consecutive addresses (SoA arrays): 256 B per wave-load
+__global__ void kStream4( const float* __restrict__ p, uint64_t n, float* out )
+{
+	float acc = 0;
+	for( uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x ) acc += p[i];
+	if( acc == 12345.678f ) out[0] = acc;
+}
+// ... and the matching store
+__global__ void kStore4( float* __restrict__ p, uint64_t n )
+{
+	for( uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x ) p[i] = (float)i;
+}
 __global__ void kGather( const uint32_t* __restrict__ p, uint64_t nLines, uint64_t nAccess, float* out )
 {
 	uint32_t acc = 0;
@@ -44,6 +56,10 @@ int main()
 	hipDeviceSynchronize();
 	hipLaunchKernelGGL( kGather, dim3( 4096 ), dim3( 256 ), 0, 0, (const uint32_t*)buf, bytes / 64, 1ull << 26, out );
 	hipDeviceSynchronize();
-	printf( "stream bytes %llu ; gather accesses %llu\n", 2ull << 30, 1ull << 26 );
+	hipLaunchKernelGGL( kStream4, dim3( 4096 ), dim3( 256 ), 0, 0, (const float*)buf, ( 2ull << 30 ) / 4, out );
+	hipDeviceSynchronize();
+	hipLaunchKernelGGL( kStore4, dim3( 4096 ), dim3( 256 ), 0, 0, (float*)buf, ( 2ull << 30 ) / 4 );
+	hipDeviceSynchronize();
+	printf( "stream bytes %llu ; gather accesses %llu ; 4-byte-per-lane stream read and store: %llu bytes each\n", 2ull << 30, 1ull << 26, 2ull << 30 );
 	return 0;
 }
