@@ -77,10 +77,8 @@ def stress(args, mv):
     # what the dependent pointer chase really moves: one brick (16 bytes of a 64-byte line) per two descents; sibling bricks share lines, so the
     # lines actually fetched are fewer -- taken from the committed counter passes (fabric read requests per ray) when they are there
     bricks = int(desc.sum()) // 2
-    reqs = None
-    tp = os.path.join(ROOT, "profiles", "traffic_stress.json")
-    if os.path.exists(tp):
-        reqs = json.load(open(tp)).get("read_requests_per_ray")
+    tj_stress, tj_note = committed_traffic("traffic_stress.json")
+    reqs = None if tj_stress is None else tj_stress.get("read_requests_per_ray")
     line_bytes = int((reqs * n_rays if reqs else bricks) * 64)
     gbs = algo * args.steps / el / 1e9
     print(json.dumps({
@@ -93,8 +91,9 @@ def stress(args, mv):
                    "embedded_mask": int(info.embeddedMask), "svo_build_s": round(build_s, 2), "hits": hits, "descents_per_ray": round(float(desc.mean()), 2)},
         "roofline": {"bound": "hbm", "kernel": "kTraceBatchStream<2> (tree flavour: two-level bricks)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "measured_stream_read_gbs": STREAM_READ_CEILING_GBS,
-                     "traffic": stress_traffic(n_rays), "traffic_source": "profiles/traffic_stress.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/stress_traffic.sh)",
+                     "traffic": stress_traffic(n_rays), "traffic_source": tj_note,
                      "algorithmic_bytes_per_launch": algo, "line_bytes_per_launch": line_bytes,
+                     "line_bytes_from": "committed fabric read requests per ray" if reqs else "bricks entered x 64 B (no counter passes of this build)",
                      "line_gbs": round(line_bytes * args.steps / el / 1e9, 1), "random_line_ceiling_gbs": RANDOM_LINE_CEILING_GBS,
                      "line_frac_of_ceiling": round(line_bytes * args.steps / el / 1e9 / RANDOM_LINE_CEILING_GBS, 3),
                      "bricks_entered_per_launch": bricks,
@@ -105,12 +104,23 @@ def stress(args, mv):
     }), flush=True)
 
 
-def stress_traffic(n_rays):
-    """fabric-side bytes per launch of the config-5 traversal kernel, from the committed PMC passes (HBM-side bytes cannot be read live)"""
-    p = os.path.join(ROOT, "profiles", "traffic_stress.json")
+def committed_traffic(name):
+    """profiles/<name>: fabric-side bytes per ray from separate rocprofv3 --pmc passes (HBM-side bytes cannot be read live).  Only valid for the library
+    it was measured with: the file records the source digest of that build, and a different digest means the kernel has changed since -> None."""
+    p = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(p):
-        return None
-    return int(json.load(open(p))["traffic_bytes_per_ray"] * n_rays)
+        return None, "no committed counter passes"
+    tj = json.load(open(p))
+    from massivevoxelraytracing_amd import build as B
+    if tj.get("source_digest") != B.source_digest():
+        return None, "profiles/%s was measured with another build of the library (source digest differs): stale, not reported" % name
+    return tj, tj["_source"]
+
+
+def stress_traffic(n_rays):
+    """fabric-side bytes per launch of the config-5 traversal kernel, from the committed PMC passes of THIS build (else None)"""
+    tj, _ = committed_traffic("traffic_stress.json")
+    return None if tj is None else int(tj["traffic_bytes_per_ray"] * n_rays)
 
 
 def cpu_primary(args):
@@ -386,11 +396,12 @@ def main():
         trace_ms = ss["traceKernelMs"]
         achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):  # HBM-side bytes cannot be read live: separate rocprofv3 --pmc passes of `bench.py --serial-only` (tools/final_profiles.sh)
-            tj = json.load(open(tpath))
-            if tj.get("scene") == args.scene and tj.get("grid_res") == args.grid_res and (W, H) == (1920, 1080):
-                traffic, traffic_src = int(tj["traffic_bytes_per_ray"] * ss["rays"] / launches), tj["_source"]
+        # HBM-side bytes cannot be read live: separate rocprofv3 --pmc passes of `bench.py --serial-only` (tools/final_profiles.sh), valid for the build they were taken with
+        tj, traffic_src = committed_traffic("traffic_latest.json")
+        if tj is not None and tj.get("scene") == args.scene and tj.get("grid_res") == args.grid_res and (W, H) == (1920, 1080):
+            traffic = int(tj["traffic_bytes_per_ray"] * ss["rays"] / launches)
+        elif tj is not None:
+            traffic_src = "profiles/traffic_latest.json is for the default workload"
         roofline = {
             "bound": "hbm", "kernel": "kPtTraceStream", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
