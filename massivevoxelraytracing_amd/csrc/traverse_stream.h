@@ -64,9 +64,19 @@
 						 // waves per SIMD) 600 Mrays/s, 8 slots 630, 16 slots (1 wave per SIMD) 404 -- the evictions cost, the occupancy does not
 #endif
 #define MVRT_RING_OF( FL ) ( ( FL ) == 0 ? MVRT_RING_EMBED : ( ( FL ) == 2 ? MVRT_RING_TREE : 4 ) )
-#ifndef MVRT_REFILL_MIN
-#define MVRT_REFILL_MIN 28 // refill once this many lanes are idle (or all of them); 20 until a refill also walked the hint's path (r03: 20 / 28 / 36 -> 67.2 / 65.8 / 70.9 ms per 36 launches)
+// refill once this many lanes are idle (or all of them).  Embedded flavour: 28 since a refill also replays the hint's path (r03: 20 / 28 / 36 -> 67.2 / 65.8 / 70.9 ms
+// per 36 launches of the headline).  Tree flavour (config 5: every node visit waits for HBM, an idle lane is a lost fetch slot): 4 / 8 / 12 / 16 / 20 / 28 ->
+// 679 / 706 / 706 / 694 / 676 / 640 Mrays/s: 12.  Plain indices: 20 as in round 2.
+#ifndef MVRT_REFILL_MIN_EMBED
+#define MVRT_REFILL_MIN_EMBED 28
 #endif
+#ifndef MVRT_REFILL_MIN_TREE
+#define MVRT_REFILL_MIN_TREE 12
+#endif
+#ifndef MVRT_REFILL_MIN_OTHER
+#define MVRT_REFILL_MIN_OTHER 20
+#endif
+#define MVRT_REFILL_MIN_OF( FL ) ( ( FL ) == 0 ? MVRT_REFILL_MIN_EMBED : ( ( FL ) == 2 ? MVRT_REFILL_MIN_TREE : MVRT_REFILL_MIN_OTHER ) )
 
 // ---- start below the root (embedded flavour) -------------------------------------------------------------------------------------------
 // The reference starts every ray at the root (voxCommon.hpp:306-312).  A secondary ray of the path tracer starts ON the voxel its path just
@@ -873,7 +883,7 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 			missM |= mMiss;
 			actM &= ~( mHit | mMiss );
 			const int nAct = __builtin_popcount( (uint32_t)actM ) + __builtin_popcount( (uint32_t)( actM >> 32 ) ); // (two 32-bit counts: a 64-bit one is compared on the VALU)
-			if( nAct == 0 || ( nAct <= 64 - MVRT_REFILL_MIN && !exhausted ) ) break;
+			if( nAct == 0 || ( nAct <= 64 - MVRT_REFILL_MIN_OF( FL ) && !exhausted ) ) break;
 		}
 		st = LANE( hitM ) ? 3u : ( LANE( missM ) ? 2u : st );
 		childMask = LANE( mFirst ) ? 8u : ( ( LANE( cmX ) ? 1u : 0u ) | ( LANE( cmY ) ? 2u : 0u ) | ( LANE( cmZ ) ? 4u : 0u ) );

@@ -21,7 +21,7 @@ bad = 0
 def scene_list():
     t = bunny_tris(); c, e = position_colors(t)
     yield "bunny", t.reshape(-1, 3), c.reshape(-1, 3), e.reshape(-1, 3)
-    for name, fn in (("dragon stand-in", scenes.dragon_standin), ("rtcamp stand-in", scenes.rtcamp_standin), ("cave stand-in", scenes.cave_standin)):
+    for name, fn in (("dragon stand-in", scenes.dragon_standin), ("rtcamp stand-in", scenes.rtcamp_standin), ("cave stand-in", scenes.cave_standin), ("tunnel stand-in", scenes.tunnel_standin)):
         v, c, e = fn(0.25)
         yield name, v, c, e
 for name, v, c, e in scene_list():
