@@ -225,3 +225,25 @@ def test_tiny_frames_empty_tile_shares_and_handle_lifetimes(mv):
     d.updateScene(v, white, black, None, lo, ext / res, 128)
     d.step(None, cam)
     assert d.read_framebuffer()[: 64 * 36, 3].min() == 32
+
+
+def test_a_hint_that_names_no_voxel_does_not_fault(mv):
+    """mvrt_trace_batch_hinted documents a hint without a voxel as an error the library does not detect: the results of such rays are unspecified,
+    but nothing may be read outside the prefix tables (codes beyond the grid, cells that are empty) and the call comes back"""
+    tris = bunny_tris()
+    v = tris.reshape(-1, 3)
+    lo = v.min(0)
+    dps = np.float32((v.max(0) - lo).max() / 256)
+    svo = mv.IntersectorOctreeGPU()
+    svo.build(v, None, None, None, lo, dps, 256)
+    rng = np.random.default_rng(5)
+    n = 50_000
+    ro = (lo + rng.random((n, 3)) * dps * 256).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    junk = rng.integers(0, 2**63, n, dtype=np.uint64)          # codes far beyond a 256^3 grid
+    empty = rng.integers(0, 2**24, n, dtype=np.uint64)         # cells of the grid, almost all of them empty
+    for hints in (junk, empty):
+        out = svo.intersect_hinted(ro, rd, hints)
+        assert np.isfinite(out["t"]).all() and len(out["t"]) == n
+    plain = svo.intersect(ro, rd, want_descents=True)
+    assert np.array_equal(svo.intersect_hinted(ro, rd, np.full(n, 2**64 - 1, np.uint64))["t"], plain["t"])  # "no hint" for every ray
