@@ -250,52 +250,18 @@ MVRT_DI f3 closestBary( f3 v0, f3 v1, f3 v2, f3 P )
 	return bc / ( bc.x + bc.y + bc.z );
 }
 
-// voxCount (EMIT = false, voxKernel.cu:58-90) and voxelize (EMIT = true, :91-166) share one body
-template <bool EMIT>
-__global__ void __launch_bounds__( 128 ) kVoxelize( const float* __restrict__ verts, const float* __restrict__ cols, const float* __restrict__ emis, uint32_t nTri,
-													 unsigned long long* counter, f3 origin, float dps, int gridRes, uint64_t* __restrict__ mortonOut,
-													 uint64_t* __restrict__ attrOut, int conservative )
+// voxCount (EMIT = false, voxKernel.cu:58-90) and voxelize (EMIT = true, :91-166) share one body.
+// The reference gives every triangle one thread, whatever its size; a wall of two triangles across a 4096^3 grid is then 16.7 M cell tests on ONE lane (seconds,
+// with 63 lanes of its wave and the rest of the chip idle).  Here a lane only does its own triangle when its footprint is small; triangles whose projected bounding
+// rectangle exceeds VOX_BIG_CELLS cells are done by the whole WAVE afterwards, one after the other, the columns of the footprint dealt to the 64 lanes.  Which lane
+// emits which voxel -- and so the order of the dumped list -- differs from the reference's; nothing downstream depends on it: the list is sorted by Morton code and the
+// attributes of duplicates are integer sums (voxKernel.cu:194-220).
+#define VOX_BIG_CELLS 2048
+MVRT_DI uint32_t voxColumns( const VT& c, float dps, int x0, int xStep, bool emit, f3 v0, f3 v1, f3 v2, f3 c0, f3 c1, f3 c2, f3 e0, f3 e1, f3 e2, uint64_t* __restrict__ mortonOut,
+							 uint64_t* __restrict__ attrOut, uint64_t dst )
 {
-	uint32_t iTri = blockIdx.x * blockDim.x + threadIdx.x;
-	if( iTri >= nTri ) return;
-	f3 v0 = loadV( verts, (uint64_t)iTri * 3 ), v1 = loadV( verts, (uint64_t)iTri * 3 + 1 ), v2 = loadV( verts, (uint64_t)iTri * 3 + 2 );
-	VT c;
-	c.init( v0, v1, v2, origin, dps, gridRes, conservative != 0 );
-	uint32_t nVoxels = 0;
-	for( int x = c.lox; x <= c.hix; x++ )
-	{
-		i2 yr = c.yRange( x, dps );
-		for( int y = yr.x; y <= yr.y; y++ )
-		{
-			i2 zr = c.zRange( x, y, dps );
-			for( int z = zr.x; z <= zr.y; z++ )
-			{
-				if( c.intersect( c.point( x, y, z, dps ) ) ) nVoxels++;
-			}
-		}
-	}
-	if( !EMIT )
-	{
-		if( nVoxels ) atomicAdd( counter, (unsigned long long)nVoxels );
-		return;
-	}
-	if( nVoxels == 0 ) return;
-	uint64_t dst = atomicAdd( counter, (unsigned long long)nVoxels );
-	f3 c0 = mk3( 1, 1, 1 ), c1 = c0, c2 = c0, e0 = mk3( 0, 0, 0 ), e1 = e0, e2 = e0; // voxUtil.hpp:49-61 defaults
-	if( cols )
-	{
-		c0 = loadV( cols, (uint64_t)iTri * 3 );
-		c1 = loadV( cols, (uint64_t)iTri * 3 + 1 );
-		c2 = loadV( cols, (uint64_t)iTri * 3 + 2 );
-	}
-	if( emis )
-	{
-		e0 = loadV( emis, (uint64_t)iTri * 3 );
-		e1 = loadV( emis, (uint64_t)iTri * 3 + 1 );
-		e2 = loadV( emis, (uint64_t)iTri * 3 + 2 );
-	}
 	uint32_t k = 0;
-	for( int x = c.lox; x <= c.hix; x++ )
+	for( int x = x0; x <= c.hix; x += xStep )
 	{
 		i2 yr = c.yRange( x, dps );
 		for( int y = yr.x; y <= yr.y; y++ )
@@ -305,21 +271,106 @@ __global__ void __launch_bounds__( 128 ) kVoxelize( const float* __restrict__ ve
 			{
 				f3 p = c.point( x, y, z, dps );
 				if( !c.intersect( p ) ) continue;
-				int cx, cy, cz; // VTContext::i -> unProjectPlane, :110-122,313-316
-				if( c.major == 0 ) { cx = x; cy = y; cz = z; }
-				else if( c.major == 1 ) { cx = z; cy = x; cz = y; }
-				else { cx = y; cy = z; cz = x; }
-				mortonOut[dst + k] = mortonEncode( cx, cy, cz );
-				f3 bc = closestBary( v0, v1, v2, p );
-				f3 bColor = c1 * bc.x + c2 * bc.y + c0 * bc.z;	 // bc.x * c1 + bc.y * c2 + bc.z * c0, voxKernel.cu:148
-				f3 bEmission = e1 * bc.x + e2 * bc.y + e0 * bc.z; // :149
-				uint64_t a = (uint64_t)(uint8_t)( bColor.x * 255.0f + 0.5f ) | (uint64_t)(uint8_t)( bColor.y * 255.0f + 0.5f ) << 8 |
-							 (uint64_t)(uint8_t)( bColor.z * 255.0f + 0.5f ) << 16 | 255ull << 24 | (uint64_t)(uint8_t)( bEmission.x * 255.0f + 0.5f ) << 32 |
-							 (uint64_t)(uint8_t)( bEmission.y * 255.0f + 0.5f ) << 40 | (uint64_t)(uint8_t)( bEmission.z * 255.0f + 0.5f ) << 48 | 255ull << 56;
-				attrOut[dst + k] = a;
+				if( emit )
+				{
+					int cx, cy, cz; // VTContext::i -> unProjectPlane, :110-122,313-316
+					if( c.major == 0 ) { cx = x; cy = y; cz = z; }
+					else if( c.major == 1 ) { cx = z; cy = x; cz = y; }
+					else { cx = y; cy = z; cz = x; }
+					mortonOut[dst + k] = mortonEncode( cx, cy, cz );
+					f3 bc = closestBary( v0, v1, v2, p );
+					f3 bColor = c1 * bc.x + c2 * bc.y + c0 * bc.z;	 // bc.x * c1 + bc.y * c2 + bc.z * c0, voxKernel.cu:148
+					f3 bEmission = e1 * bc.x + e2 * bc.y + e0 * bc.z; // :149
+					uint64_t a = (uint64_t)(uint8_t)( bColor.x * 255.0f + 0.5f ) | (uint64_t)(uint8_t)( bColor.y * 255.0f + 0.5f ) << 8 |
+								 (uint64_t)(uint8_t)( bColor.z * 255.0f + 0.5f ) << 16 | 255ull << 24 | (uint64_t)(uint8_t)( bEmission.x * 255.0f + 0.5f ) << 32 |
+								 (uint64_t)(uint8_t)( bEmission.y * 255.0f + 0.5f ) << 40 | (uint64_t)(uint8_t)( bEmission.z * 255.0f + 0.5f ) << 48 | 255ull << 56;
+					attrOut[dst + k] = a;
+				}
 				k++;
 			}
 		}
+	}
+	return k;
+}
+template <bool EMIT>
+__global__ void __launch_bounds__( 128 ) kVoxelize( const float* __restrict__ verts, const float* __restrict__ cols, const float* __restrict__ emis, uint32_t nTri,
+													 unsigned long long* counter, f3 origin, float dps, int gridRes, uint64_t* __restrict__ mortonOut,
+													 uint64_t* __restrict__ attrOut, int conservative )
+{
+	const uint32_t iTri = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	const f3 white = mk3( 1, 1, 1 ), black = mk3( 0, 0, 0 ); // voxUtil.hpp:49-61 defaults
+	bool big = false;
+	if( iTri < nTri )
+	{
+		f3 v0 = loadV( verts, (uint64_t)iTri * 3 ), v1 = loadV( verts, (uint64_t)iTri * 3 + 1 ), v2 = loadV( verts, (uint64_t)iTri * 3 + 2 );
+		VT c;
+		c.init( v0, v1, v2, origin, dps, gridRes, conservative != 0 );
+		big = (long long)( c.hix - c.lox + 1 ) * (long long)( c.hiy - c.loy + 1 ) > VOX_BIG_CELLS;
+		if( !big )
+		{
+			const uint32_t nVoxels = voxColumns( c, dps, c.lox, 1, false, v0, v1, v2, white, white, white, black, black, black, nullptr, nullptr, 0 );
+			if( !EMIT )
+			{
+				if( nVoxels ) atomicAdd( counter, (unsigned long long)nVoxels );
+			}
+			else if( nVoxels )
+			{
+				const uint64_t dst = atomicAdd( counter, (unsigned long long)nVoxels );
+				f3 c0 = white, c1 = white, c2 = white, e0 = black, e1 = black, e2 = black;
+				if( cols )
+				{
+					c0 = loadV( cols, (uint64_t)iTri * 3 );
+					c1 = loadV( cols, (uint64_t)iTri * 3 + 1 );
+					c2 = loadV( cols, (uint64_t)iTri * 3 + 2 );
+				}
+				if( emis )
+				{
+					e0 = loadV( emis, (uint64_t)iTri * 3 );
+					e1 = loadV( emis, (uint64_t)iTri * 3 + 1 );
+					e2 = loadV( emis, (uint64_t)iTri * 3 + 2 );
+				}
+				voxColumns( c, dps, c.lox, 1, true, v0, v1, v2, c0, c1, c2, e0, e1, e2, mortonOut, attrOut, dst );
+			}
+		}
+	}
+	// ---- the big triangles of this wave, one after the other, by all 64 lanes (every lane of the wave reaches this point) ----
+	unsigned long long todo = __ballot( big );
+	while( todo )
+	{
+		const uint32_t src = (uint32_t)__builtin_ctzll( todo );
+		todo &= todo - 1ull;
+		const uint32_t t = ( blockIdx.x * blockDim.x + ( threadIdx.x & ~63u ) ) + src; // the triangle of lane `src` of this wave
+		f3 v0 = loadV( verts, (uint64_t)t * 3 ), v1 = loadV( verts, (uint64_t)t * 3 + 1 ), v2 = loadV( verts, (uint64_t)t * 3 + 2 );
+		VT c;
+		c.init( v0, v1, v2, origin, dps, gridRes, conservative != 0 );
+		const uint32_t mine = voxColumns( c, dps, c.lox + (int)lane, 64, false, v0, v1, v2, white, white, white, black, black, black, nullptr, nullptr, 0 );
+		uint32_t incl = mine; // inclusive prefix over the lanes
+		for( int o = 1; o < 64; o <<= 1 )
+		{
+			const uint32_t up = __shfl_up( incl, o, 64 );
+			if( (int)lane >= o ) incl += up;
+		}
+		const uint32_t total = __shfl( incl, 63, 64 );
+		if( total == 0 ) continue;
+		unsigned long long base = 0;
+		if( lane == 0 ) base = atomicAdd( counter, (unsigned long long)total );
+		if( !EMIT ) continue;
+		base = (unsigned long long)__shfl( (uint32_t)base, 0, 64 ) | ( (unsigned long long)__shfl( (uint32_t)( base >> 32 ), 0, 64 ) << 32 );
+		f3 c0 = white, c1 = white, c2 = white, e0 = black, e1 = black, e2 = black;
+		if( cols )
+		{
+			c0 = loadV( cols, (uint64_t)t * 3 );
+			c1 = loadV( cols, (uint64_t)t * 3 + 1 );
+			c2 = loadV( cols, (uint64_t)t * 3 + 2 );
+		}
+		if( emis )
+		{
+			e0 = loadV( emis, (uint64_t)t * 3 );
+			e1 = loadV( emis, (uint64_t)t * 3 + 1 );
+			e2 = loadV( emis, (uint64_t)t * 3 + 2 );
+		}
+		voxColumns( c, dps, c.lox + (int)lane, 64, true, v0, v1, v2, c0, c1, c2, e0, e1, e2, mortonOut, attrOut, base + ( incl - mine ) );
 	}
 }
 

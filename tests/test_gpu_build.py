@@ -93,6 +93,44 @@ def test_procedural_scene_build(mv, O):
     assert_same_svo(O, mv, svo, sc)
 
 
+@pytest.mark.parametrize("res", [256, 2048])
+def test_huge_triangles_are_voxelized_by_the_whole_wave(mv, O, res):
+    """the reference voxelizes every triangle on one thread whatever its size (voxKernel.cu:58-166); here triangles with a large footprint are done by the whole wave,
+    columns dealt to the lanes, which changes who emits which voxel but not the voxel list: walls of two triangles across the grid in all three major axes (incl. a
+    slanted one with colours and emission), mixed with the bunny's small triangles in the same waves -- voxels, attributes and nodes equal the oracle's, also in
+    conservative mode.  (At 2048^3 a wall is 4.2 M cells: seconds on one lane, milliseconds here.)"""
+    import time
+    small = bunny_tris()[:3000].reshape(-1, 3)
+    lo, hi = small.min(0), small.max(0)
+    a, b = lo - 0.3, hi + 0.3
+    walls = np.array([
+        [[a[0], a[1], a[2]], [b[0], a[1], a[2]], [b[0], a[1], b[2]]], [[a[0], a[1], a[2]], [b[0], a[1], b[2]], [a[0], a[1], b[2]]],   # floor (major y)
+        [[a[0], a[1], a[2]], [a[0], b[1], a[2]], [a[0], b[1], b[2]]], [[a[0], a[1], a[2]], [a[0], b[1], b[2]], [a[0], a[1], b[2]]],   # wall (major x)
+        [[a[0], a[1], b[2]], [b[0], a[1], b[2]], [b[0], b[1], b[2]]],                                                                   # half a wall (major z)
+        [[a[0], a[1], a[2]], [b[0], b[1], a[2] + 0.2], [a[0] + 0.1, b[1], b[2]]],                                                       # slanted
+    ], np.float32).reshape(-1, 3)
+    v = np.concatenate([small[:1500], walls[:9], small[1500:], walls[9:]], axis=0).astype(np.float32)
+    rng = np.random.default_rng(3)
+    cols = rng.random(v.shape).astype(np.float32)
+    emis = np.where(rng.random((len(v), 1)) < 0.1, rng.random(v.shape), 0.0).astype(np.float32)
+    from massivevoxelraytracing_amd import scenes
+    origin, dps = scenes.bounding_grid(v, res)
+    for flags in (0, 4):
+        svo = mv.IntersectorOctreeGPU()
+        t0 = time.perf_counter()
+        svo.build(v, cols, emis, None, origin, dps, res, flags=flags)
+        mv.synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 5.0, dt
+        if flags == 0 or res == 256:
+            m, at = O.voxelize(v.reshape(-1, 9), origin, dps, res, cols.reshape(-1, 9), emis.reshape(-1, 9), six_separating=(flags == 0))
+            dumped = len(m)
+            m, at, he = O.merge_voxels(m, at)
+            sc = O.Scene(O.build_octree(m, res), at, origin, dps, res, he)
+            sc.morton, sc.dumped = m, dumped
+            assert_same_svo(O, mv, svo, sc)
+
+
 def test_tiny_and_degenerate_inputs(mv, O):
     one = np.array([[0.1, 0.2, 0.3, 0.9, 0.25, 0.35, 0.4, 0.8, 0.7]], np.float32)
     for res in (2, 4, 32):
