@@ -714,7 +714,8 @@ MVRT_DI f3 voxelEmission( const SvoDev& s, uint32_t vIndex, bool withScale ) // 
 #ifndef MVRT_SHADE_WAVES
 #define MVRT_SHADE_WAVES 5 // waves per SIMD the shade kernel is register-budgeted for
 #endif
-__global__ void __launch_bounds__( CBLOCK, MVRT_SHADE_WAVES ) kPtShade( PtParams P, int stage, int inSet )
+template <int WAVES> // register budget: waves per SIMD the kernel is compiled for
+__global__ void __launch_bounds__( CBLOCK, WAVES ) kPtShade( PtParams P, int stage, int inSet )
 {
 	__shared__ uint32_t waveCnt[CBLOCK / WAVE];
 	const uint64_t n = P.buf.liveCount[stage];
@@ -964,7 +965,17 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 							stage < MVRT_MAX_DEPTH ? buf.liveCount + stage + 1 : (uint32_t*)nullptr, buf.stats, nKinds, shadowKind );
 		PROF_END();
 		PROF_BEGIN( MVRT_K_SHADE );
-		hipLaunchKernelGGL( kPtShade, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
+		{
+			// Two builds of the kernel: stages 0 and 1 -- where most paths END (69 % of the primaries of an open scene miss) and the work per path is loads and a few adds --
+			// run the 8-waves-per-SIMD build (64 VGPRs, 44 bytes of scratch that the dying paths never touch); the deeper stages, whose paths mostly survive and run
+			// the ~2000-instruction shading, the 5-wave build.  r03, serial-mode shade time per 4 steps, stages {} / {0} / {0,1} / {1..8} / all on the 8-wave build:
+			// dragon 16.6 / 15.8 / 14.9 / 15.6 / 14.6 ms, closed cave 133.7 / 132.5 / 133.3 / 137.6 / 136.8 (tools/sweep_shade.sh)
+			static const int dense = (int)mvrtKnob( "MVRT_SHADE8_STAGES", 3 );
+			if( ( dense >> stage ) & 1 )
+				hipLaunchKernelGGL( kPtShade<8>, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
+			else
+				hipLaunchKernelGGL( kPtShade<MVRT_SHADE_WAVES>, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
+		}
 		PROF_END();
 		if( buf.dbgTasks && stage < MVRT_MAX_DEPTH ) // debug capture: the compacted survivor list this stage wrote (parity of the compaction indices)
 			MVRT_HIP( hipMemcpyAsync( buf.dbgTasks + (uint64_t)stage * buf.cap, buf.set[setIdx ^ 1].task, nSamples * 4, hipMemcpyDeviceToDevice, stream ) );
