@@ -971,10 +971,14 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 			// the ~2000-instruction shading, the 5-wave build.  r03, serial-mode shade time per 4 steps, stages {} / {0} / {0,1} / {1..8} / all on the 8-wave build:
 			// dragon 16.6 / 15.8 / 14.9 / 15.6 / 14.6 ms, closed cave 133.7 / 132.5 / 133.3 / 137.6 / 136.8 (tools/sweep_shade.sh)
 			static const int dense = (int)mvrtKnob( "MVRT_SHADE8_STAGES", 3 );
+			// The grid-stride grids hold exactly the workgroups that are RESIDENT at once (8 / 5 per CU): r02 launched 8 per CU for the 5-wave build too, and the three
+			// that had to wait for a slot ran as a second, thin round -- most of what the 8-wave build seemed to gain.  5-wave build with 8 / 6 / 5 workgroups per CU:
+			// dragon 16.6 / 14.1 / 14.0 ms of shade time per 4 serial steps, cave 133.7 / 132.3 / 129.2
+			static const int bpc8 = (int)mvrtKnob( "MVRT_SHADE_BPC8", 8 ), bpc5 = (int)mvrtKnob( "MVRT_SHADE_BPC5", 5 );
 			if( ( dense >> stage ) & 1 )
-				hipLaunchKernelGGL( kPtShade<8>, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
+				hipLaunchKernelGGL( kPtShade<8>, dim3( persistentGrid( nSamples, CBLOCK, nCUs, bpc8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
 			else
-				hipLaunchKernelGGL( kPtShade<MVRT_SHADE_WAVES>, dim3( persistentGrid( nSamples, CBLOCK, nCUs, 8 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
+				hipLaunchKernelGGL( kPtShade<MVRT_SHADE_WAVES>, dim3( persistentGrid( nSamples, CBLOCK, nCUs, bpc5 ) ), dim3( CBLOCK ), 0, stream, P, stage, setIdx );
 		}
 		PROF_END();
 		if( buf.dbgTasks && stage < MVRT_MAX_DEPTH ) // debug capture: the compacted survivor list this stage wrote (parity of the compaction indices)
