@@ -179,12 +179,12 @@ int launchCopyKids( const Node64* nodes, uint64_t nNodes, uint32_t* kids, hipStr
 // the children array and stores the reference it arrives at (index | mask << 24; 0 when the prefix leaves the octree: never looked up)
 __global__ void __launch_bounds__( 256 ) kBuildPrefixRefs( const uint32_t* __restrict__ kids, uint32_t rootRef, uint32_t tabLevels, uint32_t* __restrict__ table )
 {
-	const uint32_t total = 0x249249u & ( ( 1u << ( 3u * ( tabLevels + 1u ) ) ) - 1u ); // sum of 8^l, l = 0..tabLevels
+	const uint32_t total = 0x49249249u & ( ( 1u << ( 3u * ( tabLevels + 1u ) ) ) - 1u ); // sum of 8^l, l = 0..tabLevels
 	for( uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256 )
 	{
 		uint32_t l = 0;
-		while( ( 0x249249u & ( ( 1u << ( 3u * ( l + 1u ) ) ) - 1u ) ) <= e ) l++; // level of entry e
-		const uint32_t p = e - ( 0x249249u & ( ( 1u << ( 3u * l ) ) - 1u ) );
+		while( ( 0x49249249u & ( ( 1u << ( 3u * ( l + 1u ) ) ) - 1u ) ) <= e ) l++; // level of entry e
+		const uint32_t p = e - ( 0x49249249u & ( ( 1u << ( 3u * l ) ) - 1u ) );
 		uint32_t ref = rootRef;
 		bool alive = true;
 		for( uint32_t k = 0; k < l && alive; k++ )
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__( 256 ) kBuildPrefixRefs( const uint32_t* __res
 }
 int launchBuildPrefixRefs( const uint32_t* kids, uint32_t rootRef, uint32_t tabLevels, uint32_t* table, hipStream_t stream )
 {
-	const uint32_t total = 0x249249u & ( ( 1u << ( 3u * ( tabLevels + 1u ) ) ) - 1u );
+	const uint32_t total = 0x49249249u & ( ( 1u << ( 3u * ( tabLevels + 1u ) ) ) - 1u );
 	hipLaunchKernelGGL( kBuildPrefixRefs, dim3( cappedGrid( total ) ), dim3( 256 ), 0, stream, kids, rootRef, tabLevels, table );
 	MVRT_HIP( hipGetLastError() );
 	return 0;

@@ -97,7 +97,7 @@
 #endif
 MVRT_HDI uint32_t hintLevelsOf( uint32_t levels ) { return levels == 0u ? 0u : ( levels - 1u < MVRT_HINT_MAX ? levels - 1u : MVRT_HINT_MAX ); }
 MVRT_HDI uint32_t hintTabLevelsOf( uint32_t levels ) { return hintLevelsOf( levels ); }
-MVRT_HDI uint32_t prefixTabOffset( uint32_t l ) { return 0x249249u & ( ( 1u << ( 3u * l ) ) - 1u ); } // (8^l - 1) / 7: entries of the tables of fewer levels
+MVRT_HDI uint32_t prefixTabOffset( uint32_t l ) { return 0x49249249u & ( ( 1u << ( 3u * l ) ) - 1u ); } // (8^l - 1) / 7: entries of the tables of fewer levels
 MVRT_HDI uint64_t prefixTabEntries( uint32_t levels ) { return (uint64_t)prefixTabOffset( hintTabLevelsOf( levels ) + 1u ); }
 // the hint of a ray that starts on the voxel at `path` (a full root -> voxel path, 3 bits per level)
 // (masked to the hint's 3 bits per level: a code beyond the grid -- only a caller of mvrt_trace_batch_hinted can pass one -- must not index past the prefix tables)
