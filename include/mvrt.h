@@ -112,7 +112,8 @@ int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_t numberOfNo
 int mvrt_svo_get_info( const mvrt_svo* svo, mvrt_svo_info* info );
 int mvrt_svo_set_emission_scale( mvrt_svo* svo, float scale ); /* m_emissionScale (:273) */
 /* bytes of the device structure the traversal and mvrt_svo_download work from (the reference's layout would be numberOfNodes * 68):
- * 64-byte lines per node (+ a 16 MiB prefix table) for DAG octrees; for GPU-built octrees WITHOUT node sharing whose masks are not embedded
+ * 64-byte lines per node (+ a 16 MiB prefix table, the 32-byte children arrays and prefix tables the traversal reads and, for octrees built here, the cell index
+ * that turns a hit voxel's path into its index: ~25 bytes per voxel) for DAG octrees; for GPU-built octrees WITHOUT node sharing whose masks are not embedded
  * ("tree" flavour: MVRT_BUILD_NO_DAG with >= 0xFFFFFF nodes or MVRT_BUILD_NO_EMBEDDED_MASK) 5 bytes per node + one 16-byte two-level brick
  * per node of every second level (four bricks share a 64-byte line). */
 uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo );

@@ -146,6 +146,8 @@ struct mvrt_svo
 	DevBuf kids;				// embedded flavour: children[8] per node, 32 B per node (what the traversal reads)
 	DevBuf topTable;			// per-prefix start of the nVoxelsPSum walk (SvoDev::topTable), embedded flavour
 	uint32_t topLevels = 0;
+	DevBuf cellBlocks, cellEntries; // SvoDev::cellBlocks / cellEntries, only after build()
+	uint32_t cellBits = 0;
 	mutable DevBuf wsBuf;		// traversal workspace (spill rows + cursor), sized on demand
 	mutable DevBuf pathBuf;
 	mutable TraceWorkspace ws = { nullptr, 0, nullptr, nullptr, 0, nullptr };
@@ -176,6 +178,9 @@ struct mvrt_svo
 		topTable.release();
 		kids.release();
 		topLevels = 0;
+		cellBlocks.release();
+		cellEntries.release();
+		cellBits = 0;
 		float es = info.emissionScale;
 		memset( &info, 0, sizeof( info ) );
 		info.emissionScale = es;
@@ -223,6 +228,9 @@ struct mvrt_svo
 		d.kids = kids.as<uint32_t>();
 		d.topTable = topTable.as<uint2>();
 		d.topLevels = topLevels;
+		d.cellBlocks = cellEntries.p ? cellBlocks.as<uint32_t>() : nullptr;
+		d.cellEntries = cellEntries.as<uint2>();
+		d.cellBits = cellBits;
 		d.tree = tree;
 		d.treeRoot = treeRoot;
 		d.leafPsumIsPopcount = leafPsumIsPopcount;
@@ -336,6 +344,34 @@ MVRT_EXPORT int mvrt_svo_upload( mvrt_svo* svo, const void* nodes68Host, uint32_
 	return 0;
 }
 
+// SvoDev::cellBlocks / cellEntries from the sorted voxel codes of a build (not for the tree flavour, whose traversal reports voxel indices itself)
+static int buildCellIndex( mvrt_svo* s, hipStream_t st )
+{
+	s->cellBlocks.release();
+	s->cellEntries.release();
+	s->cellBits = 0;
+	static const int on = (int)mvrtKnob( "MVRT_CELL_INDEX", 1 );
+	const uint32_t L = s->info.levels;
+	if( !on || s->tree || !s->morton || s->info.numberOfVoxels == 0 || L == 0 || L > 14u ) return 0;
+	static const uint32_t blockBits = (uint32_t)mvrtKnob( "MVRT_CELL_BITS", 9 );
+	const uint32_t cellBits = 3u * ( L - 1u ) < blockBits ? 3u * ( L - 1u ) : blockBits; // 8 x 8 x 8 cells per block (fewer in octrees of fewer than 4 levels)
+	const uint64_t nBlockCodes = 1ull << ( 3u * ( L - 1u ) - cellBits );
+	DevBuf cnt;
+	if( cnt.alloc( 4 ) || s->cellBlocks.alloc( nBlockCodes * 4 ) ) return 1;
+	MVRT_HIP( hipMemsetAsync( cnt.p, 0, 4, st ) );
+	MVRT_HIP( hipMemsetAsync( s->cellBlocks.p, 0xFF, nBlockCodes * 4, st ) );
+	if( launchNumberCellBlocks( s->morton, s->info.numberOfVoxels, cellBits, s->cellBlocks.as<uint32_t>(), cnt.as<uint32_t>(), st ) ) return 1;
+	uint32_t nBlocks = 0;
+	MVRT_HIP( hipMemcpyAsync( &nBlocks, cnt.p, 4, hipMemcpyDeviceToHost, st ) );
+	MVRT_HIP( hipStreamSynchronize( st ) );
+	const uint64_t bytes = ( (uint64_t)nBlocks << cellBits ) * sizeof( uint2 );
+	if( s->cellEntries.alloc( bytes ) ) return 1;
+	MVRT_HIP( hipMemsetAsync( s->cellEntries.p, 0, bytes, st ) );
+	if( launchFillCellIndex( s->morton, s->info.numberOfVoxels, cellBits, s->cellBlocks.as<uint32_t>(), s->cellEntries.as<uint2>(), st ) ) return 1;
+	s->cellBits = cellBits;
+	return 0;
+}
+
 static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origin[3], float dps, int gridRes )
 {
 	svo->nodes = r.nodes;
@@ -358,6 +394,7 @@ static int adoptBuild( mvrt_svo* svo, const SvoBuildResult& r, const float origi
 	setBounds( svo, origin, dps, gridRes );
 	MVRT_HIP( hipMemcpy( &svo->rootMask, svo->masks + ( r.nNodes - 1 ), 1, hipMemcpyDeviceToHost ) );
 	if( buildTopTable( svo, nullptr ) ) return 1;
+	if( buildCellIndex( svo, nullptr ) ) return 1;
 	MVRT_HIP( hipDeviceSynchronize() );
 	return 0;
 }
@@ -404,7 +441,7 @@ MVRT_EXPORT uint64_t mvrt_svo_traversal_bytes( const mvrt_svo* svo )
 	if( !svo || !svo->nodes ) return 0;
 	const uint64_t n = svo->info.numberOfNodes;
 	if( svo->tree ) return (uint64_t)svo->nBricks * sizeof( uint4 ) + n * 5;
-	return n * sizeof( Node64 ) + n + ( svo->psumCold ? n * 32 : 0 ) + svo->topTable.bytes + svo->kids.bytes;
+	return n * sizeof( Node64 ) + n + ( svo->psumCold ? n * 32 : 0 ) + svo->topTable.bytes + svo->kids.bytes + svo->cellBlocks.bytes + svo->cellEntries.bytes;
 }
 MVRT_EXPORT const void* mvrt_svo_node_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->nodes : nullptr; }
 MVRT_EXPORT const void* mvrt_svo_attribute_buffer_dev( const mvrt_svo* svo ) { return svo ? svo->attrs : nullptr; }

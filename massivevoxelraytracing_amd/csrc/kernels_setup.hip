@@ -204,6 +204,47 @@ int launchBuildPrefixRefs( const uint32_t* kids, uint32_t rootRef, uint32_t tabL
 	MVRT_HIP( hipGetLastError() );
 	return 0;
 }
+// cell index (mvrt_common.h SvoDev::cellBlocks / cellEntries) from the sorted voxel codes of a build.  shift = 3 + cellBits: a voxel code without its last
+// `shift` bits is its block.  Pass 1 numbers the occupied blocks (the first voxel of a block takes the next number: which block gets which number depends on
+// the order the waves arrive in, what is stored under it does not); pass 2 writes the entry of every occupied cell (the thread of a cell's first voxel owns it).
+__global__ void __launch_bounds__( 256 ) kNumberCellBlocks( const uint64_t* __restrict__ morton, uint64_t n, uint32_t shift, uint32_t* __restrict__ blocks, uint32_t* __restrict__ counter )
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if( i >= n ) return;
+	const uint64_t b = morton[i] >> shift;
+	if( i != 0 && ( morton[i - 1] >> shift ) == b ) return;
+	blocks[b] = atomicAdd( counter, 1u );
+}
+__global__ void __launch_bounds__( 256 ) kFillCellIndex( const uint64_t* __restrict__ morton, uint64_t n, uint32_t cellBits, const uint32_t* __restrict__ blocks, uint2* __restrict__ entries )
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if( i >= n ) return;
+	const uint64_t cell = morton[i] >> 3;
+	if( i != 0 && ( morton[i - 1] >> 3 ) == cell ) return;
+	uint32_t mask = 0;
+	for( uint64_t j = i; j < n && j < i + 8; j++ )
+	{
+		const uint64_t c = morton[j];
+		if( ( c >> 3 ) != cell ) break;
+		mask |= 1u << ( (uint32_t)c & 7u );
+	}
+	// rank of the cell's first voxel = what nVoxelsPSum adds up to along its path; the mask ranks its voxels
+	entries[( (uint64_t)blocks[cell >> cellBits] << cellBits ) | ( (uint32_t)cell & ( ( 1u << cellBits ) - 1u ) )] = make_uint2( (uint32_t)i, mask );
+}
+int launchNumberCellBlocks( const uint64_t* morton, uint64_t n, uint32_t cellBits, uint32_t* blocks, uint32_t* counterDev, hipStream_t stream )
+{
+	if( n == 0 ) return 0;
+	hipLaunchKernelGGL( kNumberCellBlocks, dim3( divUp( n, 256 ) ), dim3( 256 ), 0, stream, morton, n, 3u + cellBits, blocks, counterDev );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
+int launchFillCellIndex( const uint64_t* morton, uint64_t n, uint32_t cellBits, const uint32_t* blocks, uint2* entries, hipStream_t stream )
+{
+	if( n == 0 ) return 0;
+	hipLaunchKernelGGL( kFillCellIndex, dim3( divUp( n, 256 ) ), dim3( 256 ), 0, stream, morton, n, cellBits, blocks, entries );
+	MVRT_HIP( hipGetLastError() );
+	return 0;
+}
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream )
 {
 	hipLaunchKernelGGL( kBuildTopTable, dim3( cappedGrid( 1ull << ( 3 * k ) ) ), dim3( 256 ), 0, stream, nodes, rootIndex, k, table );

@@ -98,6 +98,9 @@ int launchCopyKids( const Node64* nodes, uint64_t nNodes, uint32_t* kids, hipStr
 int launchBuildTopTable( const Node64* nodes, uint32_t rootIndex, uint32_t k, uint2* table, hipStream_t stream ); // embedded flavour only
 // embedded flavour: node reference (index | mask << 24) per path prefix of 0..tabLevels levels, level l at prefixTabOffset( l ) (traverse_stream.h)
 int launchBuildPrefixRefs( const uint32_t* kids, uint32_t rootRef, uint32_t tabLevels, uint32_t* table, hipStream_t stream );
+// cell index of a build (SvoDev::cellBlocks / cellEntries) from its sorted voxel codes: number the occupied blocks (blocks[] preset to ~0, counter to 0), then fill the entries (zeroed)
+int launchNumberCellBlocks( const uint64_t* morton, uint64_t n, uint32_t cellBits, uint32_t* blocks, uint32_t* counterDev, hipStream_t stream );
+int launchFillCellIndex( const uint64_t* morton, uint64_t n, uint32_t cellBits, const uint32_t* blocks, uint2* entries, hipStream_t stream );
 int launchHdriSat( const float4* pixels, int w, int h, double* satF64, uint32_t* satOut, int cosWeighted, f3 axis, hipStream_t stream );
 
 // GPU SVO construction (svo_build.hip)

@@ -179,6 +179,12 @@ struct SvoDev
 	// tree flavour (svo_build.hip): `nodes` are two-level bricks, treeRoot is where the traversal starts (a brick index, or a voxel index for a
 	// one-level octree); hits report the voxel index directly
 	uint32_t tree, treeRoot;
+	// octrees built here (not the tree flavour): the CELL INDEX (voxelIndexFromPath, traverse_stream.h).  A cell = a parent of voxels (last-but-one level), a block =
+	// the 8 x 8 x 8 cells below one node of the fourth level above the voxels.  cellBlocks[block code] = number of the block's dense array of 512 entries
+	// { Morton rank of the cell's first voxel, mask of its voxels } in cellEntries (~0 = no voxel in the block); null = walk nVoxelsPSum
+	const uint32_t* cellBlocks;
+	const uint2* cellEntries;
+	uint32_t cellBits; // bits of a cell code that index inside a block: 9, fewer for octrees of fewer than 4 levels
 	uint32_t leafPsumIsPopcount; // embedded flavour: nVoxelsPSum of the parents of voxels = exclusive popcount of their mask (every octree this library builds; checked for uploads)
 };
 

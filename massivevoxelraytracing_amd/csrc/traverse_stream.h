@@ -117,9 +117,26 @@ struct StreamHit
 
 // vIndex of the voxel at `path` = sum of nVoxelsPSum along root -> voxel (voxCommon.hpp:388-391).  Done by the
 // CONSUMER of a hit (dense kernels, every lane busy), not inside the divergent traversal loop.
+//
+// Octrees built by this library also carry the CELL INDEX (SvoDev::cellBlocks, kernels_setup.hip kFillCellIndex): nVoxelsPSum sums along a path are the RANK of
+// the voxel in Morton order (the reference numbers voxels depth first, children in index order, voxKernel.cu:296-329), and the builder has that order in hand --
+// so per occupied cell of the last-but-one level (a parent of voxels, per PATH, not per shared DAG node) { rank of its first voxel, mask of its voxels } is
+// stored in a dense 512-entry array per occupied 8 x 8 x 8 block of cells, found through a dense table over the block codes: the index of a hit voxel is two
+// gathers (the second one into lines that neighbouring hits share) + a popcount instead of a dependent 64-byte line per level below the top table.  Same
+// integers as the walk for every voxel that exists; uploaded octrees (any nVoxelsPSum, no Morton order at hand) keep the walk.
 MVRT_DI uint32_t voxelIndexFromPath( const SvoDev& s, uint64_t path )
 {
 	if( s.tree ) return (uint32_t)path; // tree flavour: the traversal already reports the voxel's index (first voxel of its parent + rank)
+	if( s.cellBlocks )
+	{
+		const uint64_t cell = path >> 3;
+		const uint32_t b = s.cellBlocks[cell >> s.cellBits];
+		if( b != 0xFFFFFFFFu ) // (always, for the path of a voxel that exists)
+		{
+			const uint2 e = s.cellEntries[( (uint64_t)b << s.cellBits ) | ( (uint32_t)cell & ( ( 1u << s.cellBits ) - 1u ) )];
+			return e.x + (uint32_t)__popc( e.y & ( ( 1u << ( (uint32_t)path & 7u ) ) - 1u ) );
+		}
+	}
 	uint32_t n = s.rootIndex, v = 0, l0 = 0;
 	if( s.topLevels ) // one table lookup replaces the first topLevels dependent gathers
 	{

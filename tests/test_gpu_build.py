@@ -189,3 +189,43 @@ def test_conservative_voxelization_mode(mv, O, res):
         assert np.array_equal(got[f], nodes_w[f]), f
     six = O.build_scene_from_triangles(tris, res, cols, emis)
     assert len(morton_w) > len(six.morton) and np.isin(six.morton, morton_w).all()
+
+
+@pytest.mark.parametrize("res,flags", [(2, 0), (4, 0), (8, 0), (16, 0), (64, 0), (512, 0), (1024, 0), (256, 2)])
+def test_cell_index_gives_the_rank_the_psum_walk_gives(mv, O, res, flags):
+    """An octree BUILT here resolves a hit voxel's index through the cell index (Morton rank of the cell's first voxel + popcount: two gathers), an UPLOADED one by
+    walking nVoxelsPSum along the path as the reference does (voxCommon.hpp:388-391).  Same node array, same rays: the two must agree voxel for voxel -- and with the
+    oracle -- at every block shape (octrees of fewer than 4 levels have blocks of fewer than 8 x 8 x 8 cells) and for the plain-index flavour (flags = 2: masks not embedded)."""
+    tris = bunny_tris()
+    v = tris.reshape(-1, 3)
+    from massivevoxelraytracing_amd import scenes
+    origin, dps = scenes.bounding_grid(v, res)
+    built = mv.IntersectorOctreeGPU()
+    built.build(v, None, None, None, origin, dps, res, flags=flags)
+    nodes, attrs, morton = built.download(want_morton=True)
+    walked = mv.IntersectorOctreeGPU()
+    walked.upload(nodes, attrs, origin, dps, res, 0, embeddedMask=(flags & 2) == 0)
+    sc = O.build_scene_from_triangles(tris, res, embed=(flags & 2) == 0)
+    rng = np.random.default_rng(res)
+    lo, hi = sc.bounds()
+    n = 200_000
+    ro = ((lo + hi) / 2 + (rng.random((n, 3)) - 0.5) * (hi - lo).max() * 2.5).astype(np.float32)
+    ro[: n // 4] = (lo + rng.random((n // 4, 3)) * (hi - lo)).astype(np.float32)  # a quarter starts inside the grid
+    rd = ((lo + rng.random((n, 3)) * (hi - lo)) - ro).astype(np.float32)
+    a = built.intersect(ro, rd)
+    b = walked.intersect(ro, rd)
+    ref = sc.trace(ro, rd, threads=8)
+    hit = ref["t"] != O.MAX_FLOAT
+    assert hit.sum() > n // 20
+    for r in (a, b):
+        assert np.array_equal(r["t"], ref["t"])
+        assert np.array_equal(r["vIndex"][hit], ref["vIndex"][hit])
+    # every voxel, not only the ones random rays reach: a ray straight down onto each voxel centre from just above it hits THAT voxel or one above it in the column;
+    # where it hits the voxel itself the index must be its Morton rank
+    xyz = np.array([O.morton_decode(int(m)) for m in morton[:: max(1, len(morton) // 50_000)]], np.float64)
+    centre = (np.asarray(origin, np.float64) + (xyz + 0.5) * float(dps))
+    ro2 = (centre + np.array([0.0, 0.75 * float(dps), 0.0])).astype(np.float32)
+    rd2 = np.tile(np.array([0.0, -1.0, 0.0], np.float32), (len(ro2), 1))
+    a2, b2, ref2 = built.intersect(ro2, rd2), walked.intersect(ro2, rd2), sc.trace(ro2, rd2, threads=8)
+    h2 = ref2["t"] != O.MAX_FLOAT
+    assert np.array_equal(a2["t"], ref2["t"]) and np.array_equal(a2["vIndex"][h2], ref2["vIndex"][h2]) and np.array_equal(b2["vIndex"][h2], ref2["vIndex"][h2])
