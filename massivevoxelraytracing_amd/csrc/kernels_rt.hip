@@ -322,10 +322,11 @@ MVRT_DI uint32_t blockRank( bool keep, uint32_t* waveCnt /* LDS, 4 entries */ )
 // nBlocks is read from device memory when nDev != null (n = *nDev items).  Tiles of 4096 counts: every thread owns four consecutive counts
 // (one 16-byte load and store, coalesced), scans them, the workgroup scans the 1024 thread sums (wave shuffles + 16 wave totals in LDS) and a
 // running total carries over to the next tile.  The count arrays are padded to a multiple of 4 entries (allocWorkSlot, mvrt_compact_indices).
-__global__ void __launch_bounds__( 1024 ) kScanBlockCounts( uint32_t* __restrict__ blockCount, uint64_t nItemsHost, const uint32_t* __restrict__ nItemsDev,
+template <int THREADS>
+__global__ void __launch_bounds__( THREADS ) kScanBlockCounts( uint32_t* __restrict__ blockCount, uint64_t nItemsHost, const uint32_t* __restrict__ nItemsDev,
 															 uint32_t* __restrict__ totalOut, unsigned long long* __restrict__ rayStats = nullptr, int nKinds = 0, int shadowKind = 0 )
 {
-	__shared__ uint32_t waveTot[16];
+	__shared__ uint32_t waveTot[THREADS / WAVE];
 	__shared__ uint32_t carryLds;
 	uint64_t nItems = nItemsDev ? (uint64_t)*nItemsDev : nItemsHost;
 	if( rayStats && threadIdx.x == 0 ) // ray accounting of the stage that was just traced (intersect() calls)
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__( 1024 ) kScanBlockCounts( uint32_t* __restrict
 	const uint32_t nBlocks = (uint32_t)( ( nItems + CBLOCK - 1 ) / CBLOCK );
 	const uint32_t lane = threadIdx.x & ( WAVE - 1 ), wave = threadIdx.x / WAVE;
 	uint32_t carry = 0;
-	for( uint32_t base = 0; base < nBlocks; base += 4096 )
+	for( uint32_t base = 0; base < nBlocks; base += THREADS * 4 )
 	{
 		const uint32_t i0 = base + threadIdx.x * 4;
 		uint4 c = make_uint4( 0u, 0u, 0u, 0u );
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__( 1024 ) kScanBlockCounts( uint32_t* __restrict
 		__syncthreads();
 		uint32_t before = carry;
 		for( uint32_t w = 0; w < wave; w++ ) before += waveTot[w];
-		if( threadIdx.x == 1023 ) carryLds = before + incl;
+		if( threadIdx.x == THREADS - 1 ) carryLds = before + incl;
 		const uint32_t e0 = before + incl - mine;
 		if( i0 + 3 < nBlocks ) *(uint4*)( blockCount + i0 ) = make_uint4( e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z );
 		else if( i0 < nBlocks ) // the last, partial quad: nothing is written past nBlocks
@@ -392,7 +393,7 @@ int launchCompactIndices( const uint8_t* keep, uint64_t n, uint32_t* dstIndex, u
 {
 	int grid = persistentGrid( n, CBLOCK, numCUs(), 8 );
 	hipLaunchKernelGGL( kCountFlags, dim3( grid ), dim3( CBLOCK ), 0, stream, keep, n, blockScratch );
-	hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, blockScratch, n, (const uint32_t*)nullptr, kept, (unsigned long long*)nullptr, 0, 0 );
+	hipLaunchKernelGGL( kScanBlockCounts<1024>, dim3( 1 ), dim3( 1024 ), 0, stream, blockScratch, n, (const uint32_t*)nullptr, kept, (unsigned long long*)nullptr, 0, 0 );
 	hipLaunchKernelGGL( kRankFlags, dim3( grid ), dim3( CBLOCK ), 0, stream, keep, n, blockScratch, dstIndex );
 	MVRT_HIP( hipGetLastError() );
 	return 0;
@@ -729,6 +730,7 @@ __global__ void __launch_bounds__( CBLOCK, WAVES ) kPtShade( PtParams P, int sta
 		const bool valid = i < n;
 		bool alive = false;
 		uint32_t task = 0, vIndex = 0;
+		uint2 attr = make_uint2( 0u, 0u );
 		uint64_t hitPath = 0;
 		int nMajor = 0;
 		float t = MVRT_MAXF;
@@ -744,6 +746,7 @@ __global__ void __launch_bounds__( CBLOCK, WAVES ) kPtShade( PtParams P, int sta
 			// the persistent traversal reports the hit voxel's path; its index is summed here, all lanes together
 			hitPath = hit ? P.buf.hitPath[i] : 0ull;
 			vIndex = hit ? voxelIndexFromPath( P.svo, hitPath ) : 0u;
+			if( hit ) attr = P.svo.attrs[vIndex]; // colour and emission of the hit voxel: one 8-byte gather serves both uses below
 			if( stage == 0 )
 			{
 				T = mk3( 1.0f, 1.0f, 1.0f );
@@ -754,7 +757,7 @@ __global__ void __launch_bounds__( CBLOCK, WAVES ) kPtShade( PtParams P, int sta
 				}
 				else // :685-689
 				{
-					L = L + T * voxelEmission( P.svo, vIndex, false );
+					L = L + T * rawReflectance( attr.y ); // (IntersectorOctreeGPU.hpp:256-259 without the scale)
 				}
 			}
 			else
@@ -776,7 +779,7 @@ __global__ void __launch_bounds__( CBLOCK, WAVES ) kPtShade( PtParams P, int sta
 				}
 				if( hit ) // :750-759
 				{
-					f3 Le = voxelEmission( P.svo, vIndex, true );
+					f3 Le = rawReflectance( attr.y ) * P.svo.emissionScale; // IntersectorOctreeGPU.hpp:256-259
 					L = L + T * Le * ( stage == 1 ? 1.0f / (float)( 1 + P.extraSamples ) : 1.0f );
 				}
 			}
@@ -802,7 +805,7 @@ __global__ void __launch_bounds__( CBLOCK, WAVES ) kPtShade( PtParams P, int sta
 			const uint32_t spp = ( P.frame.iteration + step ) * MVRT_SPP_PER_STEP + localSpp;
 			const uint32_t stream = hashCombine2( 0u, globalPixel( P.frame, localPixel ) );
 			int dim = dimBase( stage, P.hdriEnabled, P.extraSamples );
-			const f3 R = rawReflectance( P.svo.attrs[vIndex].x ); // :693
+			const f3 R = rawReflectance( attr.x ); // :693
 			const f3 hitN = getHitN( nMajor, rd );				  // :694
 			const f3 hitP = ro + rd * t;						  // :695
 			f3 nee = mk3( 0.0f, 0.0f, 0.0f );
@@ -961,8 +964,15 @@ int launchPtStep( const SvoDev& svo, const TraceWorkspace& ws, const HdriDev& hd
 		PROF_END();
 		PROF_BEGIN( MVRT_K_OTHER );
 		// survivors per block were counted by the traversal's result stores; scan them (and account the rays)
-		hipLaunchKernelGGL( kScanBlockCounts, dim3( 1 ), dim3( 1024 ), 0, stream, buf.blockCount, (uint64_t)0, (const uint32_t*)( buf.liveCount + stage ),
-							stage < MVRT_MAX_DEPTH ? buf.liveCount + stage + 1 : (uint32_t*)nullptr, buf.stats, nKinds, shadowKind );
+		// (a 256-thread workgroup: a 1024-thread one needs all 16 wave slots of one CU at once and waits -- up to a millisecond, measured on a tile share -- while the
+		// traversal waves of a sibling pass hold them)
+		static const int scanThreads = (int)mvrtKnob( "MVRT_SCAN_THREADS", 256 );
+		if( scanThreads == 1024 )
+			hipLaunchKernelGGL( kScanBlockCounts<1024>, dim3( 1 ), dim3( 1024 ), 0, stream, buf.blockCount, (uint64_t)0, (const uint32_t*)( buf.liveCount + stage ),
+								stage < MVRT_MAX_DEPTH ? buf.liveCount + stage + 1 : (uint32_t*)nullptr, buf.stats, nKinds, shadowKind );
+		else
+			hipLaunchKernelGGL( kScanBlockCounts<256>, dim3( 1 ), dim3( 256 ), 0, stream, buf.blockCount, (uint64_t)0, (const uint32_t*)( buf.liveCount + stage ),
+								stage < MVRT_MAX_DEPTH ? buf.liveCount + stage + 1 : (uint32_t*)nullptr, buf.stats, nKinds, shadowKind );
 		PROF_END();
 		PROF_BEGIN( MVRT_K_SHADE );
 		{
