@@ -357,6 +357,8 @@ static int buildCellIndex( mvrt_svo* s, hipStream_t st )
 	const uint32_t cellBits = 3u * ( L - 1u ) < blockBits ? 3u * ( L - 1u ) : blockBits; // 8 x 8 x 8 cells per block (fewer in octrees of fewer than 4 levels)
 	const uint64_t nBlockCodes = 1ull << ( 3u * ( L - 1u ) - cellBits );
 	DevBuf cnt;
+	size_t freeB0 = 0, totalB0 = 0;
+	if( hipMemGetInfo( &freeB0, &totalB0 ) != hipSuccess || nBlockCodes * 4 > freeB0 / 4 ) return 0;
 	if( cnt.alloc( 4 ) || s->cellBlocks.alloc( nBlockCodes * 4 ) ) return 1;
 	MVRT_HIP( hipMemsetAsync( cnt.p, 0, 4, st ) );
 	MVRT_HIP( hipMemsetAsync( s->cellBlocks.p, 0xFF, nBlockCodes * 4, st ) );
@@ -365,7 +367,15 @@ static int buildCellIndex( mvrt_svo* s, hipStream_t st )
 	MVRT_HIP( hipMemcpyAsync( &nBlocks, cnt.p, 4, hipMemcpyDeviceToHost, st ) );
 	MVRT_HIP( hipStreamSynchronize( st ) );
 	const uint64_t bytes = ( (uint64_t)nBlocks << cellBits ) * sizeof( uint2 );
-	if( s->cellEntries.alloc( bytes ) ) return 1;
+	// an accelerator, not a necessity: where it would take more than a quarter of what is free (or cannot be had), the octree keeps the nVoxelsPSum walk
+	size_t freeB = 0, totalB = 0;
+	if( hipMemGetInfo( &freeB, &totalB ) != hipSuccess || bytes > freeB / 4 || s->cellEntries.alloc( bytes ) )
+	{
+		(void)hipGetLastError();
+		s->cellBlocks.release();
+		s->cellEntries.release();
+		return 0;
+	}
 	MVRT_HIP( hipMemsetAsync( s->cellEntries.p, 0, bytes, st ) );
 	if( launchFillCellIndex( s->morton, s->info.numberOfVoxels, cellBits, s->cellBlocks.as<uint32_t>(), s->cellEntries.as<uint2>(), st ) ) return 1;
 	s->cellBits = cellBits;
