@@ -440,6 +440,27 @@ def test_split_small_passes_is_result_neutral(mv, O, bunny256_color, hdr):
     assert out[0][0][:, 3].min() == 16 * iters
 
 
+def test_pass_size_follows_the_frame_length_without_changing_results(mv, O, bunny256_color, hdr):
+    """Without a batch size the library merges at most HALF of the caller's frame (the steps between two clearFrameBuffer calls) into one pass, so that a frame is
+    at least two passes that overlap; the first frame cannot know its length, later ones do.  Frames of 4, 4, 1, 4 and 6 steps with moving cameras: every frame
+    equals the oracle's, whatever the pass sizes were."""
+    rgba, hw, hh = hdr
+    sc = bunny256_color
+    w, h = 96, 54
+    H = O.HDRI(rgba, hw, hh, rgba, hw, hh, math_mode=1)
+    pt = make_pt(mv, O, sc, w, h, rgba, hw, hh)
+    for f, n in enumerate((4, 4, 1, 4, 6)):
+        cams = [probe_camera(sc.origin, sc.dps, 256, focus=9.0, lens_r=0.02, offset=(6 - 0.2 * i - 0.1 * f, 4, 6)) for i in range(n)]
+        pt.clearFrameBuffer(None)
+        for c in cams:
+            pt.step(None, c)
+        got = pt.read_framebuffer()[: w * h].copy()
+        fb = np.zeros((w * h, 4), np.float32)
+        for it, c in enumerate(cams):
+            fb, _, _ = sc.render_pt(H, c, w, h, it, math_mode=1, fb=fb, threads=8)
+        assert np.array_equal(got, fb), (f, n)
+
+
 def test_trace_tie_cases_bit_exact(mv, O, bunny256):
     """rays that produce EXACT ties between mid-plane and exit times (diagonals through lattice points of the octree, dyadic
     origins): the node-visit step orders events lexicographically by (time, axis) -- the reference's min + 'x first, then y' rule --
