@@ -202,13 +202,14 @@ int mvrt_pt_set_pipeline_depth( mvrt_pt* pt, int depth );
 /* Secondary rays (shadow, extra, bounce) start below the root, hinted with the voxel their path hit last (mvrt_trace_batch_hinted); default on.
  * 0 = every ray walks from the root like the reference's.  Results are identical either way. */
 int mvrt_pt_set_origin_hints( mvrt_pt* pt, int enable );
-/* step() is DEFERRED: up to maxSteps (1 = launch immediately; 0 = automatic, the default: about two full-HD steps of samples per pass) consecutive step() calls are merged into one
+/* step() is DEFERRED: up to maxSteps (1 = launch immediately; 0 = automatic, the default: about two full-HD steps of samples per pass and at most half of the caller's
+ * frame -- the steps between its last two clear_framebuffer calls --, so that a frame is at least two passes that overlap) consecutive step() calls are merged into one
  * wavefront pass -- larger launches, identical per-sample results, additions to the frame buffer still step by step.
  * Any consumer (resolve, to_image, read, clear, join, get_stats ...) launches what is pending first. */
 int mvrt_pt_set_batch_steps( mvrt_pt* pt, int maxSteps );
 /* A SMALL pass (<= 40 M samples: a tile share of a multi-GPU frame, a small frame) of >= 2 merged steps is launched as two sibling
- * passes on two internal streams, each traversal launch restricted to half of the wave slots, so that the launch tails and the
- * shading of one overlap with the traversal of the other (default on; needs pipeline depth >= 2).  Results are unchanged. */
+ * passes on two internal streams, so that the launch tails and the shading of one overlap with the traversal of the other
+ * (default on; needs pipeline depth >= 2).  Results are unchanged. */
 int mvrt_pt_set_split_small_passes( mvrt_pt* pt, int enable );
 int mvrt_pt_join( mvrt_pt* pt, void* stream );
 int mvrt_pt_resolve( mvrt_pt* pt, void* stream );						/* :130-137, renderResolve */
