@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--build-flags", type=int, default=0, help="octree build flags (MVRT_BUILD_*); 0 = the reference's DAG with embedded masks")
     ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps first (default: one 64-spp frame, which also tells the library the frame length -- it merges at most half a frame into one pass)")
     ap.add_argument("--grid-res", type=int, default=0, help="0 = the scene's BASELINE size (dragon 2048, rtcamp 4096, cave 2048, tunnel 4096)")
     ap.add_argument("--scene", default="dragon", choices=["dragon", "rtcamp", "cave", "tunnel"])
     ap.add_argument("--width", type=int, default=1920)
