@@ -1497,6 +1497,9 @@ MVRT_EXPORT int mvrt_pt_get_stats( mvrt_pt* pt, void* stream, mvrt_pt_stats* out
 			// the lanes active in them
 			fprintf( stderr, "[util] wave-iterations %llu, active-lane-iterations %llu (%.1f%% of lane slots); refill events %llu; rays %llu -> %.2f lane-iterations per ray\n", u[2], u[3],
 					 100.0 * u[3] / ( 64.0 * ( u[2] ? u[2] : 1 ) ), u[0], (unsigned long long)s[0], (double)u[3] / (double)( s[0] ? s[0] : 1 ) );
+			unsigned long long c[2];
+			MVRT_HIP( hipMemcpy( c, pt->buf.stats + 12, sizeof( c ), hipMemcpyDeviceToHost ) );
+			fprintf( stderr, "[util] traversal waves: %.1f%% of their shader clocks in refill sections (result flush, ray loads, setup, hint replay)\n", 100.0 * (double)c[0] / (double)( c[1] ? c[1] : 1 ) );
 			unsigned long long w[48];
 			MVRT_HIP( hipMemcpy( w, pt->buf.stats + 16, sizeof( w ), hipMemcpyDeviceToHost ) );
 			for( int k = 0; k <= MVRT_MAX_DEPTH; k++ )

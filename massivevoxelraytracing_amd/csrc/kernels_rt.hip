@@ -35,7 +35,7 @@ struct BatchIO
 	uint64_t* pathOut; // scratch: resolved to vIndex by kResolveVIndex
 	uint32_t* descentsOut;
 #ifdef MVRT_UTIL_STATS
-	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0, utilRefillClocks = 0, utilTotalClocks = 0;
 	uint32_t utilMaxRayIters = 0;
 #endif
 	const uint64_t* originPath; // optional: per ray, the full path of an existing voxel (start-below-the-root hint), ~0 = none
@@ -104,7 +104,7 @@ struct PrimaryIO
 	uint64_t* pathOut;
 	uint32_t* descentsOut;
 #ifdef MVRT_UTIL_STATS
-	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0, utilRefillClocks = 0, utilTotalClocks = 0;
 	uint32_t utilMaxRayIters = 0;
 #endif
 	f3 rdKeep; // direction of the ray this lane is tracing (for the normal colour)
@@ -492,7 +492,7 @@ struct PtIO
 	int shadowKind;
 	int useHint; // stage > 0 on an embedded-mask octree: PathSet::org holds the start-below-the-root hint of every path
 #ifdef MVRT_UTIL_STATS
-	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0;
+	unsigned long long utilIters = 0, utilActive = 0, utilTailIters = 0, utilTailActive = 0, utilRefillClocks = 0, utilTotalClocks = 0;
 	uint32_t utilMaxRayIters = 0;
 #endif
 	uint32_t dNormal, dShadow, nHits; // per-lane tallies (a lane sees far fewer than 2^32 descents per launch)
@@ -582,6 +582,8 @@ __global__ void __launch_bounds__( 64, MVRT_WAVES_OF( FL ) ) kPtTraceStream( PtP
 		atomicAdd( &P.buf.stats[8 + 1], io.utilActive );
 		atomicAdd( &P.buf.stats[8 + 2], io.utilTailIters );
 		atomicAdd( &P.buf.stats[8 + 3], io.utilTailActive );
+		atomicAdd( &P.buf.stats[12], io.utilRefillClocks );
+		atomicAdd( &P.buf.stats[13], io.utilTotalClocks );
 		atomicMax( &P.buf.stats[16 + stage], io.utilTailIters ); // longest-lived wave of the stage's launches, in node-visit iterations
 		atomicAdd( &P.buf.stats[32 + stage], 1ull );			  // waves that worked
 	}

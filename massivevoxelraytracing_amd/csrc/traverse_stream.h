@@ -498,9 +498,13 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 
 #ifdef MVRT_UTIL_STATS
 	uint32_t utilVis = 0; // node-visit iterations of the lane's current ray
+	const unsigned long long utilT0 = clock64();
 #endif
 	for( ;; )
 	{
+#ifdef MVRT_UTIL_STATS
+		const unsigned long long utilTr = clock64(); // shader clocks this wave spends in refill sections (flush of results + ray loads + setup + hint replay)
+#endif
 		// ---------------- (1) refill: control only gets here when enough lanes are idle ----------------
 		const unsigned long long idleMask = __ballot( st != 1u );
 		const uint32_t nIdle = __popcll( idleMask );
@@ -700,12 +704,15 @@ MVRT_DI void traceStream( const TraceCore& s, IO& io, uint64_t total64, unsigned
 				}
 #ifdef MVRT_UTIL_STATS
 				io.utilMaxRayIters = utilVis > io.utilMaxRayIters ? utilVis : io.utilMaxRayIters;
+				io.utilRefillClocks += clock64() - utilTr;
+				io.utilTotalClocks += clock64() - utilT0;
 #endif
 				break; // every lane idle and the stream is empty: the wave retires
 			}
 		}
 
 #ifdef MVRT_UTIL_STATS
+		io.utilRefillClocks += clock64() - utilTr;
 		{
 			const unsigned long long am = __ballot( st == 1u );
 			if( lane == 0 )
