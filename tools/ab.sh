@@ -17,7 +17,7 @@ import json,sys; d=json.loads(sys.stdin.readlines()[-1]); r=d.get('roofline') or
 print('$label', d['value'], d['unit'], d['ms_per_step'], 'ms/step', $fmt)"
 }
 for r in $(seq $reps); do for spec in "$@"; do case $mode in
-  serial) run $spec "$spec" "'| serial: trace ms', round(r['avg_launch_ms']*r['launches'],2), 'shade ms', round(r['shade_share_of_kernel_time']*r['sum_kernel_ms'],2), 'trace Mrays/s', r['trace_kernel_mrays_per_s']" --steps 8 --warmup 2 ;;
+  serial) run $spec "$spec" "'| serial: trace ms', round(r['avg_launch_ms']*r['launches'],2), 'shade ms', round(r['shade_share_of_kernel_time']*r['sum_kernel_ms'],2), 'trace Mrays/s', r['trace_kernel_mrays_per_s']" --steps 8 --warmup 4 ;;
   share) for sc in ${SCENES:-dragon rtcamp}; do for t in ${TILES:-0 8}; do run $spec "$spec $sc tiles=$t" "''" --scene $sc --no-serial-pass --steps 8 --warmup 4 $([ $t != 0 ] && echo --emulate-tiles $t); done; done ;;
   stress) run $spec "$spec" "'| descents/ray', r.get('descents_per_ray')" --mode stress --steps 3 --warmup 1 ;;
 esac; done; done
