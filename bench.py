@@ -313,7 +313,7 @@ def main():
     # the collective is ordered against -- no reliance on the legacy null stream's implicit ordering
     ts = torch.cuda.current_stream().cuda_stream if dist is not None else None
 
-    def run_steps(k):
+    def run_steps(k, remainder_first=False):
         """k steps as frames of `frame_steps` steps (64 spp): per frame clear -> steps -> (N > 1: one RCCL all-gather of the per-rank accumulation
         buffers + assemble) -> the frame is complete on the device.  Everything of a frame is stream-ordered (step() is deferred / pipelined
         inside the library; join() makes the stream wait for it; N > 1: the d2d copy and the assembly are issued on torch's current stream,
@@ -321,6 +321,8 @@ def main():
         done = 0
         while done < k:
             n = min(frame_steps, k - done)
+            if remainder_first and done == 0 and k % frame_steps:
+                n = k % frame_steps  # (warmup: end on a WHOLE frame -- the library sizes its passes by the length of the caller's last frame)
             pt.clearFrameBuffer(ts)
             for _ in range(n):
                 pt.step(ts, cam)
@@ -343,7 +345,7 @@ def main():
     # ---- warmup, then the timed region: EXACTLY K steps (pipelined / batched as the library does by default) ----
     elapsed, st = None, None
     if not args.serial_only:
-        run_steps(args.warmup)
+        run_steps(args.warmup, remainder_first=True)
         elapsed, st = timed(args.steps)
 
     # ---- the non-overlapped pass the roofline comes from: pipeline depth 1, one step per pass, no sibling passes, HIP events around every
