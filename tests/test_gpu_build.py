@@ -191,7 +191,7 @@ def test_conservative_voxelization_mode(mv, O, res):
     assert len(morton_w) > len(six.morton) and np.isin(six.morton, morton_w).all()
 
 
-@pytest.mark.parametrize("res,flags", [(2, 0), (4, 0), (8, 0), (16, 0), (64, 0), (512, 0), (1024, 0), (256, 2)])
+@pytest.mark.parametrize("res,flags", [(2, 0), (4, 0), (8, 0), (16, 0), (64, 0), (512, 0), (1024, 0), (4096, 0), (256, 2)])
 def test_cell_index_gives_the_rank_the_psum_walk_gives(mv, O, res, flags):
     """An octree BUILT here resolves a hit voxel's index through the cell index (Morton rank of the cell's first voxel + popcount: two gathers), an UPLOADED one by
     walking nVoxelsPSum along the path as the reference does (voxCommon.hpp:388-391).  Same node array, same rays: the two must agree voxel for voxel -- and with the
